@@ -1,0 +1,24 @@
+# Builds the product library (HIP, gfx950) and the test-only CPU oracle.
+#   make            -> raft_amd/librq.so  oracle/librq_oracle.so
+HIPCC   ?= hipcc
+CC      ?= gcc
+ARCH    ?= gfx950
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+CSRC     = raft_amd/csrc
+
+all: raft_amd/librq.so oracle/librq_oracle.so
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h include/rq.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+raft_amd/librq.so: build/rq_kernels.o build/rq_engine.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -o $@
+
+oracle/librq_oracle.so: oracle/raft_oracle.c oracle/raft_oracle.h
+	$(CC) -O2 -std=c11 -fPIC -shared -Wall -Wextra -pthread $< -o $@
+
+clean:
+	rm -rf build raft_amd/librq.so oracle/librq_oracle.so
+
+.PHONY: all clean

@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Benchmark of the batched Raft quorum engine on MI355X.
+
+A step = one fused round (RequestVote tally + commitIndex advance with the
+log-term gather) over this rank's 1M groups x 5 peers, inputs resident in HBM.
+Input sets rotate (default 4 sets, > 512 MB in total) so that the 256 MB
+Infinity Cache cannot serve a step from on-die memory.  With N > 1 ranks the
+groups are sharded (weak scaling: 1M groups per GPU) and every step also
+all-gathers the commit/elected summary over RCCL, overlapped with the next
+step's kernel.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak
+
+
+def alg_bytes_per_group(n, what="fused"):
+    """Algorithmic bytes per group-round, int32 layout: commit 4n+20, vote 16n+17."""
+    commit = 4 * n + 20      # n match + commit + leaderTerm + logOff + gathered term ; commit'
+    vote = 16 * n + 17       # 3n planes + candTerm + candId ; n voterTerm' + 2 + 2 + 1 + 4
+    return {"commit": commit, "vote": vote, "fused": commit + vote}[what]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--groups", type=int, default=1 << 20, help="groups per GPU")
+    ap.add_argument("--peers", type=int, default=5)
+    ap.add_argument("--sets", type=int, default=4, help="rotating input sets (Infinity Cache defeat)")
+    ap.add_argument("--variant", type=lambda s: int(s, 0), default=0, help="kernel build selector")
+    ap.add_argument("--workload", choices=["fused", "mixed"], default="fused")
+    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
+    return ap.parse_args()
+
+
+def cpu_baseline(args, synth):
+    """Oracle (C restatement of raft.go: heap Node objects, one RequestVoteRPC-
+    shaped call per voter, one sort per leader) timed on the host cores, on a
+    bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    G = min(args.groups, 1 << 18)
+    b = synth.gen_fused(G, args.peers, seed=synth.DEFAULT_SEED)
+    out = {}
+    threads_all = max(1, min(16, len(os.sched_getaffinity(0))))
+    for label, threads in (("single", 1), ("multi", threads_all)):
+        sec1, _ = oracle_lib.cpu_baseline(b, 1, threads)
+        passes = max(1, min(2000, int(args.cpu_seconds / max(sec1, 1e-6))))
+        sec, _ = oracle_lib.cpu_baseline(b, passes, threads)
+        out[label] = dict(value=G * passes / sec, cores=threads, passes=passes, seconds=sec)
+    return dict(value=out["multi"]["value"], unit="decisions/s", cores=out["multi"]["cores"],
+                kind="port",
+                sample="%d groups x %d peers (same generator as the GPU workload), %d passes, %.1f s; "
+                       "C restatement of raft.go (Go toolchain absent)" % (
+                           G, args.peers, out["multi"]["passes"], out["multi"]["seconds"]),
+                single_thread_value=out["single"]["value"], host_cpus=os.cpu_count())
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from raft_amd import synth
+    from raft_amd.device import DeviceBatch, DeviceEngine
+    from raft_amd.sharded import SummaryExchange
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    G, n, S = args.groups, args.peers, max(1, args.sets)
+    eng = DeviceEngine(local_rank)
+    exchange = world > 1 and not args.no_exchange
+    ex = SummaryExchange(G, device, depth=S) if exchange else None
+
+    sets = []
+    for s in range(S):
+        seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
+        if args.workload == "fused":
+            b = synth.gen_fused(G, n, seed=seed)
+        else:
+            b = synth.gen_mixed(G, seed=seed)
+        kw = {}
+        if ex is not None:
+            kw = dict(commit_out=ex.commit_view(s), elected_bits=ex.bits_view(s))
+        sets.append(DeviceBatch(b, device, **kw))
+    if args.workload == "fused":
+        bytes_per_group = alg_bytes_per_group(n)
+        workload = "%d groups x %d peers per GPU, fused RequestVote tally + commitIndex advance with log-term gather" % (G, n)
+    else:
+        om = b.old_mask.astype("int64"); nm = b.new_mask.astype("int64")
+        members = sum(((om | nm) >> p) & 1 for p in range(16)).mean()
+        bytes_per_group = 20 * members + 37 + 4          # member slots only + two u16 masks
+        workload = "%d groups, mixed 3-9 peers + 10%% joint consensus, Zipf log lengths" % G
+    resident_mb = sum(x.bytes_resident() for x in sets) / 1e6
+
+    def step(i):
+        s = i % S
+        if ex is not None:
+            ex.wait(s)                       # slot s's previous all-gather must be done
+        eng.fused_round(sets[s], variant=args.variant, want_bits=True, status=True)
+        if ex is not None:
+            ex.exchange(s, async_op=True)
+
+    def fence():
+        if ex is not None:
+            ex.wait_all()
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        step(i)
+    ev1.record()                              # same stream as the kernels
+    if ex is not None:
+        ex.wait_all()
+    torch.cuda.synchronize(device)
+    t1 = time.perf_counter()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(device)
+    wall = t1 - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # avg launch duration on the kernel's stream
+
+    if world > 1:
+        tt = torch.tensor([wall], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        wall = float(tt.item())
+
+    if rank == 0:
+        total_groups = G * world
+        value = total_groups * args.steps / wall
+        achieved = bytes_per_group * G / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        try:
+            tj = json.load(open(args.traffic_json))
+            key = "%s_G%d_n%d" % (args.workload, G, n)
+            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+        except (OSError, ValueError):
+            pass
+        line = {
+            "metric": "quorum decisions/sec at 1M groups x 5 peers (1/8 GPU); % of HBM peak",
+            "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int32", "data": "synthetic",
+            "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
+                       "resident_mb_per_gpu": round(resident_mb, 1),
+                       "summary_allgather": bool(exchange), "variant": args.variant,
+                       "alg_bytes_per_group": bytes_per_group},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kernel_ms, "kernel": "rq_round_fixed<%d,...>" % n},
+            "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
+        }
+        if world == 1 and not args.no_cpu_baseline and args.workload == "fused":
+            line["cpu_baseline"] = cpu_baseline(args, synth)
+        print(json.dumps(line), flush=True)
+
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,243 @@
+/*
+ * rq.h -- C ABI of librq.so, the MI355X (gfx950) batched Raft quorum engine.
+ *
+ * This is the drop-in boundary a Go host (package raft, cgo) binds for the
+ * per-group quorum arithmetic of tawawhite/raft's raft.go, evaluated for very
+ * many independent Raft groups per call.  The reference has no FFI of its
+ * own; each entry point below cites the reference code it replaces.
+ *
+ * Layout (all entry points): structure-of-arrays, slot-major planes
+ *     field[p * ld + g]      p = slot (peer) 0..n-1,  g = group 0..G-1
+ * with ld >= G the plane stride in elements.  n counts every member of the
+ * cluster INCLUDING the node itself (raft.go:94-97, :114).  Terms, indices
+ * and ids are int32 (Go int is 64-bit: the host narrows and rejects values
+ * outside int32).  Leader logs are a CSR arena: group g's log is
+ *     log_term[log_off[g] .. log_off[g+1])      slot i holds log[i].TermNum
+ * indexed directly by slot (the convention of raft.go:151).
+ *
+ * Conventions: every function returns 0 (RQ_OK) or a negative RQ_E* code and
+ * never throws or aborts.  Per-group data errors that are Go panics in the
+ * reference go to status_out bits, not to the return code.  The library
+ * copies caller buffers before returning and never retains a caller pointer.
+ * Output planes may alias the matching input plane (in-place update).  One
+ * engine owns one device, one stream and one mutex; distinct engines may be
+ * used concurrently.  Every entry point makes its device current first, so a
+ * caller (goroutine) may arrive on any OS thread.
+ *
+ * No CPU fallback exists: without a usable GPU rq_engine_create fails.
+ */
+#ifndef RQ_H
+#define RQ_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RQ_VERSION 0x000100 /* 0.1.0 */
+
+/* return codes */
+#define RQ_OK            0
+#define RQ_E_ARG        -1  /* null pointer, n out of range, ld < G, ...        */
+#define RQ_E_RANGE      -2  /* size exceeds what the engine was created for    */
+#define RQ_E_NOMEM      -3  /* host or device allocation failed                */
+#define RQ_E_HIP        -4  /* HIP runtime failure, see rq_last_hip_error      */
+#define RQ_E_NODEVICE   -5  /* no such GPU / not a gfx950 device               */
+#define RQ_E_STATE      -6  /* rq_step/rq_download before rq_upload            */
+#define RQ_E_MASK       -7  /* joint: an empty configuration mask              */
+
+/* status_out bits (one byte per group) */
+#define RQ_ST_LOG_OOB   0x01u /* commit: N > commitIndex but N is outside the
+                                 leader's log; reference would panic indexing
+                                 log[N] (convention raft.go:151); no advance   */
+#define RQ_ST_EMPTY_LOG 0x02u /* vote: a voter reached lastEntry(log)
+                                 (raft.go:204, :235) with an empty log; the
+                                 reference panics; that voter does not grant  */
+
+/* voter_last_log_term value meaning "this voter's log is empty" */
+#define RQ_LOG_EMPTY INT32_MIN
+
+#define RQ_MAX_SLOTS 16
+
+typedef struct rq_engine rq_engine;
+
+int         rq_version(void);
+const char *rq_strerror(int code);
+
+/* Engine lifetime.  Device buffers for max_groups x max_slots planes and a
+ * log arena of max_log_terms entries are allocated once here.  Replaces the
+ * Go heap ownership of Node state (raft.go:15-69) for the batched path. */
+int rq_engine_create(int device, uint32_t max_groups, uint32_t max_slots,
+                     uint64_t max_log_terms, rq_engine **out);
+int rq_engine_destroy(rq_engine *e);
+int rq_last_hip_error(const rq_engine *e);      /* last hipError_t seen       */
+int rq_engine_device(const rq_engine *e);
+
+/* ---- synchronous entry points on caller (host) buffers ------------------ */
+
+/* Leader commitIndex advance for G groups of n slots.  The reference declares
+ * the state (Node.matchIndex raft.go:65-68 zero-initialised at :114-117,
+ * commitIndex :48-51, currentTerm :33-35) and never computes the rule; the
+ * rule is Raft Fig. 2 "Leaders":
+ *     N = ascending_sorted(match[0..n))[(n-1)/2]
+ *     commit' = (N > commit && log[N].TermNum == leader_term) ? N : commit
+ * match: [n][ld]; commit, leader_term, commit_out: [G]; log_off: [G+1];
+ * status_out: [G] or NULL. */
+int rq_commit_advance(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                      const int32_t *match, const int32_t *commit,
+                      const int32_t *leader_term, const uint32_t *log_off,
+                      const int32_t *log_term, int32_t *commit_out,
+                      uint8_t *status_out);
+
+/* RequestVote for all n slots of each group plus the candidate-side tally.
+ * Per slot this is exactly Node.RequestVoteRPC (raft.go:181-210) with
+ * testToAbdicateLeadership (raft.go:212-223) and lastEntry (raft.go:234-236):
+ *     cur'   = max(cur, term);  stepdown bit p = term > cur      (:219-221)
+ *     grant  = term >= cur && (votedFor == -1 || votedFor == candId)
+ *              && voterLastLogTerm <= term                       (:190-205)
+ * (lastLogIndex/lastLogTerm of the RPC are never read by the reference and
+ * are not part of this ABI; votedFor is never written.)  The tally is the
+ * caller BecomeLeader (raft.go:101) never had:
+ *     max_term = max_p cur'_p ;  elected = 2*popcount(grant) > n
+ *                                          && max_term == cand_term
+ * voter_term, voted_for, voter_last_log_term, voter_term_out: [n][ld];
+ * cand_term, cand_id, max_term: [G]; grant_mask, stepdown_mask: [G] bit p =
+ * slot p; elected: [G] 0/1; status_out: [G] or NULL. */
+int rq_vote_tally(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                  const int32_t *voter_term, const int32_t *voted_for,
+                  const int32_t *voter_last_log_term, const int32_t *cand_term,
+                  const int32_t *cand_id, int32_t *voter_term_out,
+                  uint16_t *grant_mask, uint16_t *stepdown_mask,
+                  uint8_t *elected, int32_t *max_term, uint8_t *status_out);
+
+/* Both decisions for every group in ONE kernel launch (one "group-round").
+ * status_out carries the OR of both status bit sets. */
+int rq_fused_round(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                   const int32_t *match, const int32_t *commit,
+                   const int32_t *leader_term, const uint32_t *log_off,
+                   const int32_t *log_term,
+                   const int32_t *voter_term, const int32_t *voted_for,
+                   const int32_t *voter_last_log_term, const int32_t *cand_term,
+                   const int32_t *cand_id,
+                   int32_t *commit_out, int32_t *voter_term_out,
+                   uint16_t *grant_mask, uint16_t *stepdown_mask,
+                   uint8_t *elected, int32_t *max_term, uint8_t *status_out);
+
+/* Joint-consensus variants (no counterpart in raft.go; membership there is
+ * the fixed peers slice of raft.go:26).  m slot planes, two member masks per
+ * group (bit p = slot p).  Commit: N = min(quorum index of old members,
+ * quorum index of new members), each over its own member count.  Election:
+ * strict majority of grants in BOTH configurations.  Slots outside old|new
+ * are not evaluated and their voter_term_out is left unwritten.  Mixed
+ * cluster sizes are expressed as old_mask == new_mask == (1<<n_g)-1. */
+int rq_commit_advance_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
+                            const uint16_t *old_mask, const uint16_t *new_mask,
+                            const int32_t *match, const int32_t *commit,
+                            const int32_t *leader_term, const uint32_t *log_off,
+                            const int32_t *log_term, int32_t *commit_out,
+                            uint8_t *status_out);
+int rq_vote_tally_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
+                        const uint16_t *old_mask, const uint16_t *new_mask,
+                        const int32_t *voter_term, const int32_t *voted_for,
+                        const int32_t *voter_last_log_term,
+                        const int32_t *cand_term, const int32_t *cand_id,
+                        int32_t *voter_term_out, uint16_t *grant_mask,
+                        uint16_t *stepdown_mask, uint8_t *elected,
+                        int32_t *max_term, uint8_t *status_out);
+int rq_fused_round_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
+                         const uint16_t *old_mask, const uint16_t *new_mask,
+                         const int32_t *match, const int32_t *commit,
+                         const int32_t *leader_term, const uint32_t *log_off,
+                         const int32_t *log_term,
+                         const int32_t *voter_term, const int32_t *voted_for,
+                         const int32_t *voter_last_log_term,
+                         const int32_t *cand_term, const int32_t *cand_id,
+                         int32_t *commit_out, int32_t *voter_term_out,
+                         uint16_t *grant_mask, uint16_t *stepdown_mask,
+                         uint8_t *elected, int32_t *max_term,
+                         uint8_t *status_out);
+
+/* Follower commit clamp, AppendEntriesRPC step 5 (raft.go:172-176, minInt
+ * raft.go:226-231):  commit' = lc > ci ? min(lc, last_new_index) : ci.
+ * May lower commitIndex, as the reference does.  All arrays [count]. */
+int rq_follower_clamp(rq_engine *e, uint64_t count, const int32_t *leader_commit,
+                      const int32_t *commit, const int32_t *last_new_index,
+                      int32_t *commit_out);
+
+/* ---- device-resident round: state stays in HBM between rounds ----------- */
+
+/* rq_upload copies one round's inputs (same arguments as rq_fused_round's
+ * inputs) into the engine's device buffers; rq_step runs `rounds` fused
+ * rounds on them with no host transfer (voter terms and commitIndex are
+ * updated in place, as the Go host would apply them); rq_download copies the
+ * current outputs back.  Any output pointer may be NULL to skip it. */
+int rq_upload(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+              const int32_t *match, const int32_t *commit,
+              const int32_t *leader_term, const uint32_t *log_off,
+              const int32_t *log_term,
+              const int32_t *voter_term, const int32_t *voted_for,
+              const int32_t *voter_last_log_term, const int32_t *cand_term,
+              const int32_t *cand_id);
+int rq_step(rq_engine *e, uint32_t rounds);
+int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
+                uint16_t *grant_mask, uint16_t *stepdown_mask,
+                uint8_t *elected, int32_t *max_term, uint8_t *status_out);
+
+/* ---- asynchronous launches on caller-owned DEVICE buffers --------------- *
+ * For hosts that keep group state resident in HBM (and for benchmarking
+ * without PCIe in the loop).  Every pointer is a device pointer on the
+ * engine's device; `stream` is a hipStream_t (NULL = the engine's stream).
+ * The launch is enqueued and the call returns without synchronising.
+ * elected_bits, if not NULL, receives the elected decisions packed 1 bit per
+ * group ([ceil(G/64)] uint64, bit g%64 of word g/64): the summary vector
+ * ranks exchange in a sharded deployment.  variant selects a kernel build:
+ * 0 = library default; other values are tuning knobs listed in rq_kernels.h
+ * and never change results. */
+int rq_fused_round_dev(rq_engine *e, void *stream, int variant,
+                       uint32_t G, uint32_t n, uint32_t ld,
+                       const int32_t *match, const int32_t *commit,
+                       const int32_t *leader_term, const uint32_t *log_off,
+                       const int32_t *log_term,
+                       const int32_t *voter_term, const int32_t *voted_for,
+                       const int32_t *voter_last_log_term,
+                       const int32_t *cand_term, const int32_t *cand_id,
+                       int32_t *commit_out, int32_t *voter_term_out,
+                       uint16_t *grant_mask, uint16_t *stepdown_mask,
+                       uint8_t *elected, int32_t *max_term,
+                       uint8_t *status_out, uint64_t *elected_bits);
+int rq_commit_advance_dev(rq_engine *e, void *stream, int variant,
+                          uint32_t G, uint32_t n, uint32_t ld,
+                          const int32_t *match, const int32_t *commit,
+                          const int32_t *leader_term, const uint32_t *log_off,
+                          const int32_t *log_term, int32_t *commit_out,
+                          uint8_t *status_out);
+int rq_vote_tally_dev(rq_engine *e, void *stream, int variant,
+                      uint32_t G, uint32_t n, uint32_t ld,
+                      const int32_t *voter_term, const int32_t *voted_for,
+                      const int32_t *voter_last_log_term,
+                      const int32_t *cand_term, const int32_t *cand_id,
+                      int32_t *voter_term_out, uint16_t *grant_mask,
+                      uint16_t *stepdown_mask, uint8_t *elected,
+                      int32_t *max_term, uint8_t *status_out,
+                      uint64_t *elected_bits);
+int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant,
+                             uint32_t G, uint32_t m, uint32_t ld,
+                             const uint16_t *old_mask, const uint16_t *new_mask,
+                             const int32_t *match, const int32_t *commit,
+                             const int32_t *leader_term, const uint32_t *log_off,
+                             const int32_t *log_term,
+                             const int32_t *voter_term, const int32_t *voted_for,
+                             const int32_t *voter_last_log_term,
+                             const int32_t *cand_term, const int32_t *cand_id,
+                             int32_t *commit_out, int32_t *voter_term_out,
+                             uint16_t *grant_mask, uint16_t *stepdown_mask,
+                             uint8_t *elected, int32_t *max_term,
+                             uint8_t *status_out, uint64_t *elected_bits);
+int rq_stream_sync(rq_engine *e, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RQ_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of librq.so (the C-ABI declared in include/rq.h).
+
+The library holds only gfx950 device code plus its launch plumbing; there is
+no CPU fallback here or anywhere in this package.  If the shared object is
+missing the import fails loudly and tells the caller how to build it.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librq.so")
+
+i32p = C.POINTER(C.c_int32)
+u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16)
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+u32 = C.c_uint32
+u64 = C.c_uint64
+cint = C.c_int
+
+_COMMIT_IN = [i32p, i32p, i32p, u32p, i32p]          # match commit leader_term log_off log_term
+_VOTE_IN = [i32p, i32p, i32p, i32p, i32p]            # voter_term voted_for last_log_term cand_term cand_id
+_VOTE_OUT = [i32p, u16p, u16p, u8p, i32p]            # voter_term_out grant stepdown elected max_term
+_MASKS = [u16p, u16p]
+
+# name -> argtypes; every function returns int except where noted below.
+PROTOTYPES = {
+    "rq_version": [],
+    "rq_engine_create": [cint, u32, u32, u64, C.POINTER(vp)],
+    "rq_engine_destroy": [vp],
+    "rq_last_hip_error": [vp],
+    "rq_engine_device": [vp],
+    "rq_commit_advance": [vp, u32, u32, u32] + _COMMIT_IN + [i32p, u8p],
+    "rq_vote_tally": [vp, u32, u32, u32] + _VOTE_IN + _VOTE_OUT + [u8p],
+    "rq_fused_round": [vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN + [i32p] + _VOTE_OUT + [u8p],
+    "rq_commit_advance_joint": [vp, u32, u32, u32] + _MASKS + _COMMIT_IN + [i32p, u8p],
+    "rq_vote_tally_joint": [vp, u32, u32, u32] + _MASKS + _VOTE_IN + _VOTE_OUT + [u8p],
+    "rq_fused_round_joint": [vp, u32, u32, u32] + _MASKS + _COMMIT_IN + _VOTE_IN + [i32p] + _VOTE_OUT + [u8p],
+    "rq_follower_clamp": [vp, u64, i32p, i32p, i32p, i32p],
+    "rq_upload": [vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN,
+    "rq_step": [vp, u32],
+    "rq_download": [vp, i32p] + _VOTE_OUT + [u8p],
+    # device-pointer launches: raw addresses (void*) so torch data_ptr() ints pass through
+    "rq_fused_round_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 18,
+    "rq_commit_advance_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 7,
+    "rq_vote_tally_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 12,
+    "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 20,
+    "rq_stream_sync": [vp, vp],
+}
+
+_lib = None
+
+
+class RqError(RuntimeError):
+    def __init__(self, code, where, hip=0):
+        self.code = code
+        self.hip = hip
+        msg = lib().rq_strerror(code).decode()
+        if hip:
+            msg += " [hipError %d]" % hip
+        super().__init__("%s: %s (%d)" % (where, msg, code))
+
+
+def lib():
+    """Load librq.so once.  torch (if used by the process) must own the HIP
+    runtime: it ships its own libamdhip64 with the same soname, so it is
+    imported first and librq.so then binds to the already-loaded runtime."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "raft_amd/librq.so is not built; run `make` (or __graft_entry__.build()) "
+            "in the repository root. There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (loads torch/lib/libamdhip64.so first)
+    except ImportError:
+        pass
+    l = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, args in PROTOTYPES.items():
+        fn = getattr(l, name)
+        fn.argtypes = args
+        fn.restype = cint
+    l.rq_strerror.argtypes = [cint]
+    l.rq_strerror.restype = C.c_char_p
+    _lib = l
+    return l

@@ -1,0 +1,568 @@
+// rq_engine.hip -- the rq_* C-ABI (include/rq.h): engine object, device
+// buffers, host<->device staging and launch plumbing.  All compute is in
+// rq_kernels.hip; nothing here evaluates a quorum decision on the CPU.
+#include "../../include/rq.h"
+#include "rq_kernels.h"
+
+#include <atomic>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+struct rq_engine {
+    int device = 0;
+    uint32_t max_groups = 0, max_slots = 0, ld = 0;
+    uint64_t max_log_terms = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::atomic<int> last_hip{0};
+    char *slab = nullptr;
+    // planes [max_slots][ld]
+    int32_t *match = nullptr, *voter_term = nullptr, *voted_for = nullptr, *last_log_term = nullptr;
+    // per group [ld]
+    int32_t *commit = nullptr, *leader_term = nullptr, *cand_term = nullptr, *cand_id = nullptr;
+    int32_t *max_term = nullptr;
+    uint16_t *grant = nullptr, *stepdown = nullptr, *old_mask = nullptr, *new_mask = nullptr;
+    uint8_t *elected = nullptr, *status = nullptr;
+    uint32_t *log_off = nullptr;  // [ld + 1]
+    int32_t *log_term = nullptr;  // [max_log_terms]
+    // resident round (rq_upload / rq_step / rq_download)
+    bool resident = false;
+    uint32_t res_G = 0, res_n = 0;
+};
+
+namespace {
+
+constexpr size_t kAlign = 256;
+inline size_t up(size_t x) { return (x + kAlign - 1) / kAlign * kAlign; }
+
+#define RQ_HIP(e, call)                                    \
+    do {                                                   \
+        hipError_t rq_err_ = (call);                       \
+        if (rq_err_ != hipSuccess) {                       \
+            (e)->last_hip.store((int)rq_err_);             \
+            return RQ_E_HIP;                               \
+        }                                                  \
+    } while (0)
+
+int check_shape(const rq_engine *e, uint32_t G, uint32_t n, uint32_t ld) {
+    if (!e) return RQ_E_ARG;
+    if (n < 1 || n > RQ_MAX_SLOTS || ld < G) return RQ_E_ARG;
+    if (G > e->max_groups || n > e->max_slots) return RQ_E_RANGE;
+    return RQ_OK;
+}
+
+// copy n planes of G elements, host stride ld -> device stride e->ld
+int h2d_planes(rq_engine *e, int32_t *dst, const int32_t *src, uint32_t G, uint32_t n, uint32_t ld) {
+    if (G == 0) return RQ_OK;
+    RQ_HIP(e, hipMemcpy2DAsync(dst, (size_t)e->ld * 4, src, (size_t)ld * 4, (size_t)G * 4, n,
+                               hipMemcpyHostToDevice, e->stream));
+    return RQ_OK;
+}
+int d2h_planes(rq_engine *e, int32_t *dst, const int32_t *src, uint32_t G, uint32_t n, uint32_t ld) {
+    if (G == 0) return RQ_OK;
+    RQ_HIP(e, hipMemcpy2DAsync(dst, (size_t)ld * 4, src, (size_t)e->ld * 4, (size_t)G * 4, n,
+                               hipMemcpyDeviceToHost, e->stream));
+    return RQ_OK;
+}
+int h2d(rq_engine *e, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0) return RQ_OK;
+    RQ_HIP(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+    return RQ_OK;
+}
+int d2h(rq_engine *e, void *dst, const void *src, size_t bytes) {
+    if (bytes == 0 || dst == nullptr) return RQ_OK;
+    RQ_HIP(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+    return RQ_OK;
+}
+
+#define RQ_TRY(x) do { int rq_rc_ = (x); if (rq_rc_ != RQ_OK) return rq_rc_; } while (0)
+
+// The CSR arena of one call: validates monotone offsets on the host copy the
+// caller already holds (the kernel indexes the arena with them).
+int stage_log(rq_engine *e, uint32_t G, const uint32_t *log_off, const int32_t *log_term) {
+    if (!log_off || (!log_term && G && log_off[G] != 0)) return RQ_E_ARG;
+    for (uint32_t g = 0; g < G; g++)
+        if (log_off[g + 1] < log_off[g]) return RQ_E_ARG;
+    const uint64_t total = G ? (uint64_t)log_off[G] : 0;
+    if (total > e->max_log_terms) return RQ_E_RANGE;
+    RQ_TRY(h2d(e, e->log_off, log_off, ((size_t)G + 1) * 4));
+    RQ_TRY(h2d(e, e->log_term, log_term, (size_t)total * 4));
+    return RQ_OK;
+}
+
+int check_masks(uint32_t G, uint32_t m, const uint16_t *old_mask, const uint16_t *new_mask) {
+    if (!old_mask || !new_mask) return RQ_E_ARG;
+    const uint32_t lim = m >= 16 ? 0xFFFFu : ((1u << m) - 1u);
+    for (uint32_t g = 0; g < G; g++)
+        if (!(old_mask[g] & lim) || !(new_mask[g] & lim)) return RQ_E_MASK;
+    return RQ_OK;
+}
+
+struct host_round {
+    uint32_t G, n, ld;
+    bool joint;
+    const uint16_t *old_mask, *new_mask;
+    // inputs
+    const int32_t *match, *commit, *leader_term;
+    const uint32_t *log_off;
+    const int32_t *log_term;
+    const int32_t *voter_term, *voted_for, *last_log_term, *cand_term, *cand_id;
+    // outputs
+    int32_t *commit_out, *voter_term_out;
+    uint16_t *grant_mask, *stepdown_mask;
+    uint8_t *elected;
+    int32_t *max_term;
+    uint8_t *status_out;
+};
+
+rq_round_args device_args(rq_engine *e, uint32_t G, uint32_t m, bool joint) {
+    rq_round_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = e->ld; a.m = m;
+    a.match = e->match; a.commit = e->commit; a.leader_term = e->leader_term;
+    a.log_off = e->log_off; a.log_term = e->log_term;
+    a.voter_term = e->voter_term; a.voted_for = e->voted_for;
+    a.last_log_term = e->last_log_term; a.cand_term = e->cand_term; a.cand_id = e->cand_id;
+    a.old_mask = joint ? e->old_mask : nullptr;
+    a.new_mask = joint ? e->new_mask : nullptr;
+    a.commit_out = e->commit; a.voter_term_out = e->voter_term;  // in place on device
+    a.grant_mask = e->grant; a.stepdown_mask = e->stepdown; a.elected = e->elected;
+    a.max_term = e->max_term; a.status_out = e->status; a.elected_bits = nullptr;
+    return a;
+}
+
+int stage_inputs(rq_engine *e, const host_round &h, int what) {
+    if (h.joint) {
+        RQ_TRY(check_masks(h.G, h.n, h.old_mask, h.new_mask));
+        RQ_TRY(h2d(e, e->old_mask, h.old_mask, (size_t)h.G * 2));
+        RQ_TRY(h2d(e, e->new_mask, h.new_mask, (size_t)h.G * 2));
+    }
+    if (what & RQ_WHAT_COMMIT) {
+        if (!h.match || !h.commit || !h.leader_term) return RQ_E_ARG;
+        RQ_TRY(stage_log(e, h.G, h.log_off, h.log_term));
+        RQ_TRY(h2d_planes(e, e->match, h.match, h.G, h.n, h.ld));
+        RQ_TRY(h2d(e, e->commit, h.commit, (size_t)h.G * 4));
+        RQ_TRY(h2d(e, e->leader_term, h.leader_term, (size_t)h.G * 4));
+    }
+    if (what & RQ_WHAT_VOTE) {
+        if (!h.voter_term || !h.voted_for || !h.last_log_term || !h.cand_term || !h.cand_id)
+            return RQ_E_ARG;
+        RQ_TRY(h2d_planes(e, e->voter_term, h.voter_term, h.G, h.n, h.ld));
+        RQ_TRY(h2d_planes(e, e->voted_for, h.voted_for, h.G, h.n, h.ld));
+        RQ_TRY(h2d_planes(e, e->last_log_term, h.last_log_term, h.G, h.n, h.ld));
+        RQ_TRY(h2d(e, e->cand_term, h.cand_term, (size_t)h.G * 4));
+        RQ_TRY(h2d(e, e->cand_id, h.cand_id, (size_t)h.G * 4));
+    }
+    return RQ_OK;
+}
+
+int fetch_outputs(rq_engine *e, const host_round &h, int what) {
+    if (what & RQ_WHAT_COMMIT) RQ_TRY(d2h(e, h.commit_out, e->commit, (size_t)h.G * 4));
+    if (what & RQ_WHAT_VOTE) {
+        // Joint rounds: a non-member slot on the device still holds the staged
+        // input (the kernel leaves it alone or rewrites the value it loaded), so
+        // whole-plane copies hand the caller its own value back for those slots.
+        RQ_TRY(d2h_planes(e, h.voter_term_out, e->voter_term, h.G, h.n, h.ld));
+        RQ_TRY(d2h(e, h.grant_mask, e->grant, (size_t)h.G * 2));
+        RQ_TRY(d2h(e, h.stepdown_mask, e->stepdown, (size_t)h.G * 2));
+        RQ_TRY(d2h(e, h.elected, e->elected, (size_t)h.G));
+        RQ_TRY(d2h(e, h.max_term, e->max_term, (size_t)h.G * 4));
+    }
+    RQ_TRY(d2h(e, h.status_out, e->status, (size_t)h.G));
+    return RQ_OK;
+}
+
+int run_host_round(rq_engine *e, const host_round &h, int what) {
+    RQ_TRY(check_shape(e, h.G, h.n, h.ld));
+    if ((what & RQ_WHAT_COMMIT) && !h.commit_out) return RQ_E_ARG;
+    if ((what & RQ_WHAT_VOTE) &&
+        (!h.voter_term_out || !h.grant_mask || !h.stepdown_mask || !h.elected || !h.max_term))
+        return RQ_E_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RQ_HIP(e, hipSetDevice(e->device));
+    e->resident = false;
+    if (h.G == 0) return RQ_OK;
+    RQ_TRY(stage_inputs(e, h, what));
+    rq_round_args a = device_args(e, h.G, h.n, h.joint);
+    RQ_HIP(e, rq_launch_round(a, h.n, h.joint, what, 0, e->stream));
+    RQ_TRY(fetch_outputs(e, h, what));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rq_version(void) { return RQ_VERSION; }
+
+const char *rq_strerror(int code) {
+    switch (code) {
+    case RQ_OK: return "ok";
+    case RQ_E_ARG: return "invalid argument";
+    case RQ_E_RANGE: return "size exceeds engine capacity";
+    case RQ_E_NOMEM: return "out of memory";
+    case RQ_E_HIP: return "HIP runtime error (see rq_last_hip_error)";
+    case RQ_E_NODEVICE: return "no usable gfx950 device";
+    case RQ_E_STATE: return "no resident round (call rq_upload first)";
+    case RQ_E_MASK: return "empty joint-consensus configuration mask";
+    default: return "unknown rq error";
+    }
+}
+
+int rq_engine_create(int device, uint32_t max_groups, uint32_t max_slots,
+                     uint64_t max_log_terms, rq_engine **out) {
+    if (!out) return RQ_E_ARG;
+    *out = nullptr;
+    if (device < 0 || max_groups == 0 || max_groups > 0x7FFFFFFFu - 64 || max_slots < 1 ||
+        max_slots > RQ_MAX_SLOTS || max_log_terms > 0xFFFFFFFFull)
+        return RQ_E_ARG;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device >= count) return RQ_E_NODEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return RQ_E_NODEVICE;
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RQ_E_NODEVICE;
+
+    rq_engine *e = new (std::nothrow) rq_engine();
+    if (!e) return RQ_E_NOMEM;
+    e->device = device;
+    e->max_groups = max_groups;
+    e->max_slots = max_slots;
+    e->max_log_terms = max_log_terms;
+    e->ld = (max_groups + 63u) / 64u * 64u;
+
+    const size_t plane = up((size_t)max_slots * e->ld * 4);
+    const size_t vec4 = up((size_t)e->ld * 4), vec2 = up((size_t)e->ld * 2), vec1 = up((size_t)e->ld);
+    const size_t offs = up(((size_t)e->ld + 1) * 4), arena = up((size_t)max_log_terms * 4 + 4);
+    const size_t total = 4 * plane + 5 * vec4 + 4 * vec2 + 2 * vec1 + offs + arena;
+
+    if (hipSetDevice(device) != hipSuccess) { delete e; return RQ_E_NODEVICE; }
+    hipError_t err = hipMalloc((void **)&e->slab, total);
+    if (err != hipSuccess) { delete e; return RQ_E_NOMEM; }
+    err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err != hipSuccess) { (void)hipFree(e->slab); delete e; return RQ_E_HIP; }
+    err = hipMemsetAsync(e->slab, 0, total, e->stream);
+    if (err == hipSuccess) err = hipStreamSynchronize(e->stream);
+    if (err != hipSuccess) {
+        (void)hipStreamDestroy(e->stream); (void)hipFree(e->slab); delete e; return RQ_E_HIP;
+    }
+    char *p = e->slab;
+    auto take = [&p](size_t bytes) { char *r = p; p += bytes; return r; };
+    e->match = (int32_t *)take(plane);
+    e->voter_term = (int32_t *)take(plane);
+    e->voted_for = (int32_t *)take(plane);
+    e->last_log_term = (int32_t *)take(plane);
+    e->commit = (int32_t *)take(vec4);
+    e->leader_term = (int32_t *)take(vec4);
+    e->cand_term = (int32_t *)take(vec4);
+    e->cand_id = (int32_t *)take(vec4);
+    e->max_term = (int32_t *)take(vec4);
+    e->grant = (uint16_t *)take(vec2);
+    e->stepdown = (uint16_t *)take(vec2);
+    e->old_mask = (uint16_t *)take(vec2);
+    e->new_mask = (uint16_t *)take(vec2);
+    e->elected = (uint8_t *)take(vec1);
+    e->status = (uint8_t *)take(vec1);
+    e->log_off = (uint32_t *)take(offs);
+    e->log_term = (int32_t *)take(arena);
+    *out = e;
+    return RQ_OK;
+}
+
+int rq_engine_destroy(rq_engine *e) {
+    if (!e) return RQ_E_ARG;
+    int rc = RQ_OK;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (hipSetDevice(e->device) != hipSuccess) rc = RQ_E_HIP;
+        if (e->stream) {
+            (void)hipStreamSynchronize(e->stream);
+            if (hipStreamDestroy(e->stream) != hipSuccess) rc = RQ_E_HIP;
+        }
+        if (e->slab && hipFree(e->slab) != hipSuccess) rc = RQ_E_HIP;
+    }
+    delete e;
+    return rc;
+}
+
+int rq_last_hip_error(const rq_engine *e) { return e ? e->last_hip.load() : 0; }
+int rq_engine_device(const rq_engine *e) { return e ? e->device : -1; }
+
+int rq_commit_advance(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                      const int32_t *match, const int32_t *commit,
+                      const int32_t *leader_term, const uint32_t *log_off,
+                      const int32_t *log_term, int32_t *commit_out, uint8_t *status_out) {
+    host_round h{};
+    h.G = G; h.n = n; h.ld = ld;
+    h.match = match; h.commit = commit; h.leader_term = leader_term;
+    h.log_off = log_off; h.log_term = log_term;
+    h.commit_out = commit_out; h.status_out = status_out;
+    return run_host_round(e, h, RQ_WHAT_COMMIT);
+}
+
+int rq_vote_tally(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                  const int32_t *voter_term, const int32_t *voted_for,
+                  const int32_t *voter_last_log_term, const int32_t *cand_term,
+                  const int32_t *cand_id, int32_t *voter_term_out, uint16_t *grant_mask,
+                  uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
+                  uint8_t *status_out) {
+    host_round h{};
+    h.G = G; h.n = n; h.ld = ld;
+    h.voter_term = voter_term; h.voted_for = voted_for; h.last_log_term = voter_last_log_term;
+    h.cand_term = cand_term; h.cand_id = cand_id;
+    h.voter_term_out = voter_term_out; h.grant_mask = grant_mask; h.stepdown_mask = stepdown_mask;
+    h.elected = elected; h.max_term = max_term; h.status_out = status_out;
+    return run_host_round(e, h, RQ_WHAT_VOTE);
+}
+
+int rq_fused_round(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                   const int32_t *match, const int32_t *commit, const int32_t *leader_term,
+                   const uint32_t *log_off, const int32_t *log_term,
+                   const int32_t *voter_term, const int32_t *voted_for,
+                   const int32_t *voter_last_log_term, const int32_t *cand_term,
+                   const int32_t *cand_id, int32_t *commit_out, int32_t *voter_term_out,
+                   uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
+                   int32_t *max_term, uint8_t *status_out) {
+    host_round h{};
+    h.G = G; h.n = n; h.ld = ld;
+    h.match = match; h.commit = commit; h.leader_term = leader_term;
+    h.log_off = log_off; h.log_term = log_term;
+    h.voter_term = voter_term; h.voted_for = voted_for; h.last_log_term = voter_last_log_term;
+    h.cand_term = cand_term; h.cand_id = cand_id;
+    h.commit_out = commit_out; h.voter_term_out = voter_term_out; h.grant_mask = grant_mask;
+    h.stepdown_mask = stepdown_mask; h.elected = elected; h.max_term = max_term;
+    h.status_out = status_out;
+    return run_host_round(e, h, RQ_WHAT_COMMIT | RQ_WHAT_VOTE);
+}
+
+int rq_commit_advance_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
+                            const uint16_t *old_mask, const uint16_t *new_mask,
+                            const int32_t *match, const int32_t *commit,
+                            const int32_t *leader_term, const uint32_t *log_off,
+                            const int32_t *log_term, int32_t *commit_out, uint8_t *status_out) {
+    host_round h{};
+    h.G = G; h.n = m; h.ld = ld; h.joint = true; h.old_mask = old_mask; h.new_mask = new_mask;
+    h.match = match; h.commit = commit; h.leader_term = leader_term;
+    h.log_off = log_off; h.log_term = log_term;
+    h.commit_out = commit_out; h.status_out = status_out;
+    return run_host_round(e, h, RQ_WHAT_COMMIT);
+}
+
+int rq_vote_tally_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
+                        const uint16_t *old_mask, const uint16_t *new_mask,
+                        const int32_t *voter_term, const int32_t *voted_for,
+                        const int32_t *voter_last_log_term, const int32_t *cand_term,
+                        const int32_t *cand_id, int32_t *voter_term_out, uint16_t *grant_mask,
+                        uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
+                        uint8_t *status_out) {
+    host_round h{};
+    h.G = G; h.n = m; h.ld = ld; h.joint = true; h.old_mask = old_mask; h.new_mask = new_mask;
+    h.voter_term = voter_term; h.voted_for = voted_for; h.last_log_term = voter_last_log_term;
+    h.cand_term = cand_term; h.cand_id = cand_id;
+    h.voter_term_out = voter_term_out; h.grant_mask = grant_mask; h.stepdown_mask = stepdown_mask;
+    h.elected = elected; h.max_term = max_term; h.status_out = status_out;
+    return run_host_round(e, h, RQ_WHAT_VOTE);
+}
+
+int rq_fused_round_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
+                         const uint16_t *old_mask, const uint16_t *new_mask,
+                         const int32_t *match, const int32_t *commit,
+                         const int32_t *leader_term, const uint32_t *log_off,
+                         const int32_t *log_term, const int32_t *voter_term,
+                         const int32_t *voted_for, const int32_t *voter_last_log_term,
+                         const int32_t *cand_term, const int32_t *cand_id,
+                         int32_t *commit_out, int32_t *voter_term_out, uint16_t *grant_mask,
+                         uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
+                         uint8_t *status_out) {
+    host_round h{};
+    h.G = G; h.n = m; h.ld = ld; h.joint = true; h.old_mask = old_mask; h.new_mask = new_mask;
+    h.match = match; h.commit = commit; h.leader_term = leader_term;
+    h.log_off = log_off; h.log_term = log_term;
+    h.voter_term = voter_term; h.voted_for = voted_for; h.last_log_term = voter_last_log_term;
+    h.cand_term = cand_term; h.cand_id = cand_id;
+    h.commit_out = commit_out; h.voter_term_out = voter_term_out; h.grant_mask = grant_mask;
+    h.stepdown_mask = stepdown_mask; h.elected = elected; h.max_term = max_term;
+    h.status_out = status_out;
+    return run_host_round(e, h, RQ_WHAT_COMMIT | RQ_WHAT_VOTE);
+}
+
+int rq_follower_clamp(rq_engine *e, uint64_t count, const int32_t *leader_commit,
+                      const int32_t *commit, const int32_t *last_new_index,
+                      int32_t *commit_out) {
+    if (!e || !leader_commit || !commit || !last_new_index || !commit_out) return RQ_E_ARG;
+    if (count > (uint64_t)e->max_slots * e->ld) return RQ_E_RANGE;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RQ_HIP(e, hipSetDevice(e->device));
+    e->resident = false;
+    if (count == 0) return RQ_OK;
+    const size_t bytes = (size_t)count * 4;
+    RQ_TRY(h2d(e, e->match, leader_commit, bytes));
+    RQ_TRY(h2d(e, e->voter_term, commit, bytes));
+    RQ_TRY(h2d(e, e->voted_for, last_new_index, bytes));
+    RQ_HIP(e, rq_launch_follower_clamp(count, e->match, e->voter_term, e->voted_for,
+                                       e->last_log_term, e->stream));
+    RQ_TRY(d2h(e, commit_out, e->last_log_term, bytes));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+int rq_upload(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+              const int32_t *match, const int32_t *commit, const int32_t *leader_term,
+              const uint32_t *log_off, const int32_t *log_term,
+              const int32_t *voter_term, const int32_t *voted_for,
+              const int32_t *voter_last_log_term, const int32_t *cand_term,
+              const int32_t *cand_id) {
+    RQ_TRY(check_shape(e, G, n, ld));
+    host_round h{};
+    h.G = G; h.n = n; h.ld = ld;
+    h.match = match; h.commit = commit; h.leader_term = leader_term;
+    h.log_off = log_off; h.log_term = log_term;
+    h.voter_term = voter_term; h.voted_for = voted_for; h.last_log_term = voter_last_log_term;
+    h.cand_term = cand_term; h.cand_id = cand_id;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RQ_HIP(e, hipSetDevice(e->device));
+    e->resident = false;
+    if (G) RQ_TRY(stage_inputs(e, h, RQ_WHAT_COMMIT | RQ_WHAT_VOTE));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    e->resident = true; e->res_G = G; e->res_n = n;
+    return RQ_OK;
+}
+
+int rq_step(rq_engine *e, uint32_t rounds) {
+    if (!e) return RQ_E_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->resident) return RQ_E_STATE;
+    RQ_HIP(e, hipSetDevice(e->device));
+    if (e->res_G == 0) return RQ_OK;
+    rq_round_args a = device_args(e, e->res_G, e->res_n, false);
+    for (uint32_t r = 0; r < rounds; r++)
+        RQ_HIP(e, rq_launch_round(a, e->res_n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, 0, e->stream));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
+                uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
+                int32_t *max_term, uint8_t *status_out) {
+    if (!e) return RQ_E_ARG;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->resident) return RQ_E_STATE;
+    RQ_HIP(e, hipSetDevice(e->device));
+    const uint32_t G = e->res_G;
+    RQ_TRY(d2h(e, commit_out, e->commit, (size_t)G * 4));
+    if (voter_term_out && G) RQ_TRY(d2h_planes(e, voter_term_out, e->voter_term, G, e->res_n, G));
+    RQ_TRY(d2h(e, grant_mask, e->grant, (size_t)G * 2));
+    RQ_TRY(d2h(e, stepdown_mask, e->stepdown, (size_t)G * 2));
+    RQ_TRY(d2h(e, elected, e->elected, (size_t)G));
+    RQ_TRY(d2h(e, max_term, e->max_term, (size_t)G * 4));
+    RQ_TRY(d2h(e, status_out, e->status, (size_t)G));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+// ---- device-pointer launches ----------------------------------------------
+
+static int dev_launch(rq_engine *e, void *stream, int variant, uint32_t n, bool joint, int what,
+                      const rq_round_args &a) {
+    if (!e) return RQ_E_ARG;
+    if (n < 1 || n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
+    if (what & RQ_WHAT_COMMIT)
+        if (!a.match || !a.commit || !a.leader_term || !a.log_off || !a.log_term || !a.commit_out)
+            return RQ_E_ARG;
+    if (what & RQ_WHAT_VOTE)
+        if (!a.voter_term || !a.voted_for || !a.last_log_term || !a.cand_term || !a.cand_id ||
+            !a.voter_term_out || !a.grant_mask || !a.stepdown_mask || !a.elected || !a.max_term)
+            return RQ_E_ARG;
+    if (joint && (!a.old_mask || !a.new_mask)) return RQ_E_ARG;
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
+    hipError_t err = rq_launch_round(a, n, joint, what, variant, s);
+    if (err == hipErrorInvalidValue) return RQ_E_ARG;
+    RQ_HIP(e, err);
+    return RQ_OK;
+}
+
+int rq_fused_round_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n, uint32_t ld,
+                       const int32_t *match, const int32_t *commit, const int32_t *leader_term,
+                       const uint32_t *log_off, const int32_t *log_term,
+                       const int32_t *voter_term, const int32_t *voted_for,
+                       const int32_t *voter_last_log_term, const int32_t *cand_term,
+                       const int32_t *cand_id, int32_t *commit_out, int32_t *voter_term_out,
+                       uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
+                       int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits) {
+    rq_round_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.m = n;
+    a.match = match; a.commit = commit; a.leader_term = leader_term;
+    a.log_off = log_off; a.log_term = log_term;
+    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
+    a.cand_term = cand_term; a.cand_id = cand_id;
+    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
+    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
+    a.status_out = status_out; a.elected_bits = elected_bits;
+    return dev_launch(e, stream, variant, n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
+}
+
+int rq_commit_advance_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n,
+                          uint32_t ld, const int32_t *match, const int32_t *commit,
+                          const int32_t *leader_term, const uint32_t *log_off,
+                          const int32_t *log_term, int32_t *commit_out, uint8_t *status_out) {
+    rq_round_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.m = n;
+    a.match = match; a.commit = commit; a.leader_term = leader_term;
+    a.log_off = log_off; a.log_term = log_term;
+    a.commit_out = commit_out; a.status_out = status_out;
+    return dev_launch(e, stream, variant, n, false, RQ_WHAT_COMMIT, a);
+}
+
+int rq_vote_tally_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n, uint32_t ld,
+                      const int32_t *voter_term, const int32_t *voted_for,
+                      const int32_t *voter_last_log_term, const int32_t *cand_term,
+                      const int32_t *cand_id, int32_t *voter_term_out, uint16_t *grant_mask,
+                      uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
+                      uint8_t *status_out, uint64_t *elected_bits) {
+    rq_round_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.m = n;
+    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
+    a.cand_term = cand_term; a.cand_id = cand_id;
+    a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
+    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
+    a.status_out = status_out; a.elected_bits = elected_bits;
+    return dev_launch(e, stream, variant, n, false, RQ_WHAT_VOTE, a);
+}
+
+int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t m,
+                             uint32_t ld, const uint16_t *old_mask, const uint16_t *new_mask,
+                             const int32_t *match, const int32_t *commit,
+                             const int32_t *leader_term, const uint32_t *log_off,
+                             const int32_t *log_term, const int32_t *voter_term,
+                             const int32_t *voted_for, const int32_t *voter_last_log_term,
+                             const int32_t *cand_term, const int32_t *cand_id,
+                             int32_t *commit_out, int32_t *voter_term_out, uint16_t *grant_mask,
+                             uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
+                             uint8_t *status_out, uint64_t *elected_bits) {
+    rq_round_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.m = m;
+    a.old_mask = old_mask; a.new_mask = new_mask;
+    a.match = match; a.commit = commit; a.leader_term = leader_term;
+    a.log_off = log_off; a.log_term = log_term;
+    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
+    a.cand_term = cand_term; a.cand_id = cand_id;
+    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
+    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
+    a.status_out = status_out; a.elected_bits = elected_bits;
+    return dev_launch(e, stream, variant, m, true, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
+}
+
+int rq_stream_sync(rq_engine *e, void *stream) {
+    if (!e) return RQ_E_ARG;
+    RQ_HIP(e, hipSetDevice(e->device));
+    RQ_HIP(e, hipStreamSynchronize(stream ? (hipStream_t)stream : e->stream));
+    return RQ_OK;
+}
+
+}  // extern "C"

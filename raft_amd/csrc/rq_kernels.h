@@ -1,0 +1,63 @@
+// rq_kernels.h -- launch interface between the C-ABI (rq_engine.hip) and the
+// gfx950 kernels (rq_kernels.hip).  Internal to librq.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// One round's device pointers.  Planes are field[p * ld + g].
+struct rq_round_args {
+    uint32_t G;
+    uint32_t ld;
+    uint32_t m;  // joint kernels: number of slot planes
+    // commit side (Node.matchIndex / commitIndex / currentTerm / log, raft.go:35-68)
+    const int32_t  *match;
+    const int32_t  *commit;
+    const int32_t  *leader_term;
+    const uint32_t *log_off;
+    const int32_t  *log_term;
+    // vote side (RequestVoteRPC inputs, raft.go:181-210)
+    const int32_t  *voter_term;
+    const int32_t  *voted_for;
+    const int32_t  *last_log_term;
+    const int32_t  *cand_term;
+    const int32_t  *cand_id;
+    // joint consensus member masks
+    const uint16_t *old_mask;
+    const uint16_t *new_mask;
+    // outputs
+    int32_t  *commit_out;
+    int32_t  *voter_term_out;
+    uint16_t *grant_mask;
+    uint16_t *stepdown_mask;
+    uint8_t  *elected;
+    int32_t  *max_term;
+    uint8_t  *status_out;    // may be null
+    uint64_t *elected_bits;  // may be null
+};
+
+// Kernel build selector ("variant" in the C-ABI).  Never changes results.
+//   bits 0-3  groups per thread V: 0 = library default, else 1, 2 or 4
+//   bit  4    non-temporal loads of the streamed planes
+//   bit  5    non-temporal stores of the outputs
+//   bit  6    stage the block's contiguous log-arena segment through LDS
+//             instead of gathering log[N] straight from global memory
+#define RQ_VAR_V_MASK   0x0F
+#define RQ_VAR_NT_LOAD  0x10
+#define RQ_VAR_NT_STORE 0x20
+#define RQ_VAR_LDS_LOG  0x40
+
+#define RQ_WHAT_COMMIT 1
+#define RQ_WHAT_VOTE   2
+
+// Enqueue one round on `stream`.  `what` = RQ_WHAT_COMMIT | RQ_WHAT_VOTE.
+// n is the fixed cluster size (1..16) or, with joint = true, ignored in favour
+// of a.m and the masks.  Returns hipErrorInvalidValue for shapes it rejects.
+hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint,
+                           int what, int variant, hipStream_t stream);
+
+// commit'[i] = lc[i] > ci[i] ? min(lc[i], last_new[i]) : ci[i]   (raft.go:172-176)
+hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,
+                                    const int32_t *commit,
+                                    const int32_t *last_new_index,
+                                    int32_t *commit_out, hipStream_t stream);

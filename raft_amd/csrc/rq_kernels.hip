@@ -1,0 +1,698 @@
+// rq_kernels.hip -- gfx950 (MI355X) kernels of the batched Raft quorum engine.
+//
+// One thread owns V consecutive groups (V = 1, 2 or 4) so that every plane is
+// read with one 4*V-byte load per lane: a wave reads 256*V contiguous bytes of
+// each slot plane, and the 2-byte / 1-byte per-group outputs become 4- or
+// 8-byte stores.  All quorum arithmetic stays in registers:
+//   * commit: compile-time sorting network over the n matchIndex values
+//     (v_min/v_max/v_med3), one gathered log-term load, one compare;
+//   * vote: the reference's RequestVoteRPC predicate per slot (raft.go:181-223)
+//     folded into two bit masks, popcount majority, running max of terms.
+// The kernels are HBM-bound integer work; there is no matrix-shaped step.
+#include "rq_kernels.h"
+
+#include <limits.h>
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------
+// vector load/store helpers
+// ---------------------------------------------------------------------------
+template <int V> struct i32v;
+template <> struct i32v<2> { typedef int32_t type __attribute__((ext_vector_type(2))); };
+template <> struct i32v<4> { typedef int32_t type __attribute__((ext_vector_type(4))); };
+
+// r[0..V) = p[0..V) (FULL: one aligned vector load; else first `valid` only).
+template <int V, bool NT, bool FULL>
+__device__ __forceinline__ void ld_i32(const int32_t *p, int valid, int32_t (&r)[V]) {
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int k = 0; k < V; k++) r[k] = k < valid ? p[k] : 0;
+    } else if constexpr (V == 1) {
+        r[0] = NT ? __builtin_nontemporal_load(p) : *p;
+    } else {
+        typedef typename i32v<V>::type vt;
+        const vt *vp = reinterpret_cast<const vt *>(p);
+        vt v = NT ? __builtin_nontemporal_load(vp) : *vp;
+#pragma unroll
+        for (int k = 0; k < V; k++) r[k] = v[k];
+    }
+}
+
+template <int V, bool NT, bool FULL>
+__device__ __forceinline__ void st_i32(int32_t *p, int valid, const int32_t (&r)[V]) {
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int k = 0; k < V; k++) if (k < valid) p[k] = r[k];
+    } else if constexpr (V == 1) {
+        if (NT) __builtin_nontemporal_store(r[0], p); else *p = r[0];
+    } else {
+        typedef typename i32v<V>::type vt;
+        vt v;
+#pragma unroll
+        for (int k = 0; k < V; k++) v[k] = r[k];
+        vt *vp = reinterpret_cast<vt *>(p);
+        if (NT) __builtin_nontemporal_store(v, vp); else *vp = v;
+    }
+}
+
+// V 16-bit values (low halves of r[k]) -> one 2*V-byte store.
+template <int V, bool NT, bool FULL>
+__device__ __forceinline__ void st_u16(uint16_t *p, int valid, const uint32_t (&r)[V]) {
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint16_t)r[k];
+    } else if constexpr (V == 1) {
+        *p = (uint16_t)r[0];
+    } else if constexpr (V == 2) {
+        uint32_t w = (r[0] & 0xFFFFu) | (r[1] << 16);
+        uint32_t *wp = reinterpret_cast<uint32_t *>(p);
+        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 w;
+        w[0] = (r[0] & 0xFFFFu) | (r[1] << 16);
+        w[1] = (r[2] & 0xFFFFu) | (r[3] << 16);
+        u32x2 *wp = reinterpret_cast<u32x2 *>(p);
+        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
+    }
+}
+
+// V 8-bit values -> one V-byte store.
+template <int V, bool NT, bool FULL>
+__device__ __forceinline__ void st_u8(uint8_t *p, int valid, const uint32_t (&r)[V]) {
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint8_t)r[k];
+    } else if constexpr (V == 1) {
+        *p = (uint8_t)r[0];
+    } else if constexpr (V == 2) {
+        *reinterpret_cast<uint16_t *>(p) = (uint16_t)((r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8));
+    } else {
+        uint32_t w = (r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8) | ((r[2] & 0xFFu) << 16) | (r[3] << 24);
+        uint32_t *wp = reinterpret_cast<uint32_t *>(p);
+        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
+    }
+}
+
+template <int V, bool FULL>
+__device__ __forceinline__ void ld_u16(const uint16_t *p, int valid, uint32_t (&r)[V]) {
+    if constexpr (!FULL) {
+#pragma unroll
+        for (int k = 0; k < V; k++) r[k] = k < valid ? p[k] : 0;
+    } else if constexpr (V == 1) {
+        r[0] = *p;
+    } else if constexpr (V == 2) {
+        uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+        r[0] = w & 0xFFFFu; r[1] = w >> 16;
+    } else {
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        u32x2 w = *reinterpret_cast<const u32x2 *>(p);
+        r[0] = w[0] & 0xFFFFu; r[1] = w[0] >> 16;
+        r[2] = w[1] & 0xFFFFu; r[3] = w[1] >> 16;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// quorum index: ascending_sorted(s)[(N-1)/2] = the (N/2+1)-th largest value,
+// i.e. the largest index replicated on a strict majority of the N slots.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void cex(int32_t &a, int32_t &b) {
+    int32_t lo = min(a, b), hi = max(a, b);
+    a = lo; b = hi;
+}
+__device__ __forceinline__ int32_t med3(int32_t a, int32_t b, int32_t c) {
+    return max(min(a, b), min(max(a, b), c));  // folds to v_med3_i32
+}
+
+template <int N>
+__device__ __forceinline__ int32_t quorum_index(int32_t (&s)[N]) {
+    if constexpr (N == 1) {
+        return s[0];
+    } else if constexpr (N == 2) {
+        return min(s[0], s[1]);
+    } else if constexpr (N == 3) {
+        return med3(s[0], s[1], s[2]);
+    } else if constexpr (N == 4) {
+        return min(max(min(s[0], s[1]), min(s[2], s[3])),
+                   min(max(s[0], s[1]), max(s[2], s[3])));
+    } else if constexpr (N == 5) {
+        return med3(s[4], max(min(s[0], s[1]), min(s[2], s[3])),
+                          min(max(s[0], s[1]), max(s[2], s[3])));
+    } else if constexpr (N == 6) {
+        cex(s[0], s[5]); cex(s[1], s[3]); cex(s[2], s[4]);
+        cex(s[1], s[2]); cex(s[3], s[4]);
+        cex(s[0], s[3]); cex(s[2], s[5]);
+        cex(s[0], s[1]); cex(s[2], s[3]); cex(s[4], s[5]);
+        cex(s[1], s[2]); cex(s[3], s[4]);
+        return s[2];
+    } else if constexpr (N == 7) {
+        cex(s[0], s[6]); cex(s[2], s[3]); cex(s[4], s[5]);
+        cex(s[0], s[2]); cex(s[1], s[4]); cex(s[3], s[6]);
+        cex(s[0], s[1]); cex(s[2], s[5]); cex(s[3], s[4]);
+        cex(s[1], s[2]); cex(s[4], s[6]);
+        cex(s[2], s[3]); cex(s[4], s[5]);
+        cex(s[1], s[2]); cex(s[3], s[4]); cex(s[5], s[6]);
+        return s[3];
+    } else if constexpr (N == 8) {
+        cex(s[0], s[2]); cex(s[1], s[3]); cex(s[4], s[6]); cex(s[5], s[7]);
+        cex(s[0], s[4]); cex(s[1], s[5]); cex(s[2], s[6]); cex(s[3], s[7]);
+        cex(s[0], s[1]); cex(s[2], s[3]); cex(s[4], s[5]); cex(s[6], s[7]);
+        cex(s[2], s[4]); cex(s[3], s[5]);
+        cex(s[1], s[4]); cex(s[3], s[6]);
+        cex(s[1], s[2]); cex(s[3], s[4]); cex(s[5], s[6]);
+        return s[3];
+    } else {
+        static_assert(N == 9, "fixed-size networks cover 1..9 slots");
+        cex(s[0], s[3]); cex(s[1], s[7]); cex(s[2], s[5]); cex(s[4], s[8]);
+        cex(s[0], s[7]); cex(s[2], s[4]); cex(s[3], s[8]); cex(s[5], s[6]);
+        cex(s[0], s[2]); cex(s[1], s[3]); cex(s[4], s[5]); cex(s[7], s[8]);
+        cex(s[1], s[4]); cex(s[3], s[6]); cex(s[5], s[7]);
+        cex(s[0], s[1]); cex(s[2], s[4]); cex(s[3], s[5]); cex(s[6], s[8]);
+        cex(s[2], s[3]); cex(s[4], s[5]); cex(s[6], s[7]);
+        cex(s[1], s[2]); cex(s[3], s[4]); cex(s[5], s[6]);
+        return s[4];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// One RequestVoteRPC evaluation (raft.go:181-210 with :212-223 and :234-236).
+//   stepdown : term > cur                         (:219, role := Follower :221)
+//   cur2     : max(cur, term)                     (:220)
+//   reach    : !(term < cur2) == term >= cur      (:190)
+//   grant    : reach && (votedFor == -1 || votedFor == candId)   (:202-203)
+//                    && lastEntry(log).TermNum <= term           (:204)
+//   panic    : reach && log empty                 (:204 -> :235 index panic)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void vote_slot(int32_t cur, int32_t vf, int32_t llt,
+                                          int32_t term, int32_t cid, int32_t &cur2,
+                                          uint32_t &stepdown, uint32_t &grant,
+                                          uint32_t &panic) {
+    stepdown = term > cur;
+    cur2 = max(cur, term);
+    const bool reach = term >= cur;
+    const bool empty = llt == INT_MIN;
+    panic = reach && empty;
+    grant = reach && (vf == -1 || vf == cid) && !empty && (llt <= term);
+}
+
+// Pack each thread's V elected bits (groups g0..g0+V-1) into the 1-bit-per-
+// group summary.  Must be reached by every lane of the wave.
+template <int V>
+__device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32_t G,
+                                             uint64_t *bits) {
+    if constexpr (V == 1) {
+        unsigned long long w = __ballot(field & 1u);
+        if ((threadIdx.x & 63) == 0 && g0 < G) bits[g0 >> 6] = w;
+    } else {
+        constexpr int lanes_per_word = 64 / V;
+        unsigned long long w = (unsigned long long)field << (g0 & 63);
+#pragma unroll
+        for (int o = lanes_per_word / 2; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
+        if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) bits[g0 >> 6] = w;
+    }
+}
+
+constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02;
+
+// ---------------------------------------------------------------------------
+// fixed cluster size n = N for every group
+// ---------------------------------------------------------------------------
+template <int N, int V, int WHAT, int FLAGS, bool FULL>
+__device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
+                                                     uint32_t g0, int valid) {
+    constexpr bool NTL = (FLAGS & RQ_VAR_NT_LOAD) != 0;
+    constexpr bool NTS = (FLAGS & RQ_VAR_NT_STORE) != 0;
+    constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
+    constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
+    const size_t ld = a.ld;
+
+    int32_t mt[N][V], cm[V], lt[V], off[V + 1];
+    int32_t vt[N][V], vf[N][V], ll[N][V], ct[V], ci[V];
+    uint32_t st[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) st[k] = 0;
+
+    // ---- issue every streamed load up front ----
+    if constexpr (DO_COMMIT) {
+#pragma unroll
+        for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
+        ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
+        ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
+        const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
+        int32_t o[V];
+        ld_i32<V, NTL, FULL>(offp, valid, o);
+        const int32_t oend = offp[valid];  // log_off has G+1 entries
+#pragma unroll
+        for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
+        off[V] = oend;
+    }
+    if constexpr (DO_VOTE) {
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, vt[p]);
+            ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, vf[p]);
+            ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, ll[p]);
+        }
+        ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
+        ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
+    }
+
+    // ---- commit: quorum index, then the dependent log-term gather ----
+    int32_t nq[V], gt[V];
+    bool adv[V], inb[V];
+    if constexpr (DO_COMMIT) {
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            int32_t s[N];
+#pragma unroll
+            for (int p = 0; p < N; p++) s[p] = mt[p][k];
+            nq[k] = quorum_index<N>(s);
+            const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
+            adv[k] = (k < valid) && nq[k] > cm[k];
+            inb[k] = (uint32_t)nq[k] < len;
+            gt[k] = 0;
+            if (adv[k] && inb[k]) gt[k] = a.log_term[(size_t)(uint32_t)off[k] + (uint32_t)nq[k]];
+        }
+    }
+
+    // ---- vote: per-slot predicate, tally ----
+    uint32_t el_field = 0;
+    if constexpr (DO_VOTE) {
+        uint32_t gm[V], sm[V], el[V];
+        int32_t mx[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) { gm[k] = 0; sm[k] = 0; mx[k] = INT_MIN; }
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            int32_t nt[V];
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                uint32_t sd, gr, pn;
+                vote_slot(vt[p][k], vf[p][k], ll[p][k], ct[k], ci[k], nt[k], sd, gr, pn);
+                gm[k] |= gr << p;
+                sm[k] |= sd << p;
+                mx[k] = max(mx[k], nt[k]);
+                st[k] |= pn ? kStEmptyLog : 0;
+            }
+            st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
+        }
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            el[k] = (2 * __popc(gm[k]) > N) && (mx[k] == ct[k]);
+            if (k < valid) el_field |= el[k] << k;
+        }
+        st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
+        st_u16<V, NTS, FULL>(a.stepdown_mask + g0, valid, sm);
+        st_u8<V, NTS, FULL>(a.elected + g0, valid, el);
+        st_i32<V, NTS, FULL>(a.max_term + g0, valid, mx);
+    }
+
+    // ---- commit: finish ----
+    if constexpr (DO_COMMIT) {
+        int32_t co[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
+            st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
+        }
+        st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
+    }
+    if (a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
+    return el_field;
+}
+
+template <int N, int V, int WHAT, int FLAGS>
+__global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args a) {
+    const uint64_t g0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    uint32_t el_field = 0;
+    if (g0 + V <= a.G)
+        el_field = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V);
+    else if (g0 < a.G)
+        el_field = round_fixed_body<N, V, WHAT, FLAGS, false>(a, (uint32_t)g0, (int)(a.G - g0));
+    if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
+        if (a.elected_bits) pack_elected<V>(el_field, g0, a.G, a.elected_bits);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// per-group membership: m slot planes, old/new member masks (joint consensus,
+// mixed cluster sizes).  Null masks mean "all m slots, one configuration".
+// ---------------------------------------------------------------------------
+template <int MMAX, int V, int WHAT, int FLAGS, bool FULL>
+__device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
+                                                     uint32_t g0, int valid,
+                                                     bool in_range) {
+    constexpr bool NTL = (FLAGS & RQ_VAR_NT_LOAD) != 0;
+    constexpr bool NTS = (FLAGS & RQ_VAR_NT_STORE) != 0;
+    constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
+    constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
+    const size_t ld = a.ld;
+    const uint32_t m = a.m;
+    const uint32_t lim = m >= 16 ? 0xFFFFu : ((1u << m) - 1u);
+
+    uint32_t om[V], nm[V], mem[V];
+    uint32_t anymem = 0;
+    if (in_range) {
+        if (a.old_mask) {
+            ld_u16<V, FULL>(a.old_mask + g0, valid, om);
+            ld_u16<V, FULL>(a.new_mask + g0, valid, nm);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; k++) om[k] = nm[k] = (k < valid) ? lim : 0;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < V; k++) om[k] = nm[k] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        om[k] &= lim; nm[k] &= lim;
+        mem[k] = om[k] | nm[k];
+        anymem |= mem[k];
+    }
+    // slots no lane of this wave uses are skipped with scalar branches
+    uint32_t wm = 0;
+#pragma unroll
+    for (int p = 0; p < MMAX; p++)
+        if (__ballot((anymem >> p) & 1u) != 0ull) wm |= 1u << p;
+    wm = __builtin_amdgcn_readfirstlane(wm);
+
+    uint32_t st[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) st[k] = 0;
+
+    int32_t nq[V], gt[V], cm[V], lt[V];
+    bool adv[V], inb[V];
+    if constexpr (DO_COMMIT) {
+        int32_t mt[MMAX][V];
+        int32_t off[V + 1];
+#pragma unroll
+        for (int p = 0; p < MMAX; p++) {
+#pragma unroll
+            for (int k = 0; k < V; k++) mt[p][k] = 0;
+            if ((wm >> p) & 1u) {
+                if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; }
+        off[V] = 0;
+        if (in_range) {
+            ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
+            ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
+            const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
+            int32_t o[V];
+            ld_i32<V, NTL, FULL>(offp, valid, o);
+            const int32_t oend = offp[valid];
+#pragma unroll
+            for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
+            off[V] = oend;
+        }
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            // N_cfg = max{ match_i : i in cfg, #{j in cfg : match_j >= match_i} >= |cfg|/2+1 }
+            const int majo = (__popc(om[k]) >> 1) + 1, majn = (__popc(nm[k]) >> 1) + 1;
+            int32_t no = INT_MIN, nn = INT_MIN;
+#pragma unroll
+            for (int i = 0; i < MMAX; i++) {
+                if (!((wm >> i) & 1u)) continue;
+                uint32_t ge = 0;
+#pragma unroll
+                for (int j = 0; j < MMAX; j++) {
+                    if (!((wm >> j) & 1u)) continue;
+                    ge |= (mt[j][k] >= mt[i][k]) ? (1u << j) : 0u;
+                }
+                const bool oko = ((om[k] >> i) & 1u) && __popc(ge & om[k]) >= majo;
+                const bool okn = ((nm[k] >> i) & 1u) && __popc(ge & nm[k]) >= majn;
+                no = oko ? max(no, mt[i][k]) : no;
+                nn = okn ? max(nn, mt[i][k]) : nn;
+            }
+            nq[k] = min(no, nn);
+            const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
+            adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
+            inb[k] = (uint32_t)nq[k] < len;
+            gt[k] = 0;
+            if (adv[k] && inb[k]) gt[k] = a.log_term[(size_t)(uint32_t)off[k] + (uint32_t)nq[k]];
+        }
+    }
+
+    uint32_t el_field = 0;
+    if constexpr (DO_VOTE) {
+        int32_t ct[V], ci[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) { ct[k] = 0; ci[k] = 0; }
+        if (in_range) {
+            ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
+            ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
+        }
+        uint32_t gm[V], sm[V], el[V];
+        int32_t mx[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) { gm[k] = 0; sm[k] = 0; mx[k] = INT_MIN; }
+#pragma unroll
+        for (int p = 0; p < MMAX; p++) {
+            if (!((wm >> p) & 1u)) continue;
+            if (!((anymem >> p) & 1u)) continue;
+            int32_t vt[V], vf[V], ll[V], nt[V];
+            ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, vt);
+            ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, vf);
+            ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, ll);
+            bool all_members = true;
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const bool member = (mem[k] >> p) & 1u;
+                uint32_t sd, gr, pn;
+                vote_slot(vt[k], vf[k], ll[k], ct[k], ci[k], nt[k], sd, gr, pn);
+                if (member) {
+                    gm[k] |= gr << p;
+                    sm[k] |= sd << p;
+                    mx[k] = max(mx[k], nt[k]);
+                    st[k] |= pn ? kStEmptyLog : 0;
+                } else {
+                    nt[k] = vt[k];
+                    if (k < valid) all_members = false;
+                }
+            }
+            if (all_members) {
+                st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; k++)
+                    if (k < valid && ((mem[k] >> p) & 1u)) a.voter_term_out[p * ld + g0 + k] = nt[k];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            const bool maj_old = 2 * __popc(gm[k] & om[k]) > __popc(om[k]);
+            const bool maj_new = 2 * __popc(gm[k] & nm[k]) > __popc(nm[k]);
+            el[k] = maj_old && maj_new && (mx[k] == ct[k]) && mem[k] != 0;
+            if (k < valid) el_field |= el[k] << k;
+        }
+        if (in_range) {
+            st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
+            st_u16<V, NTS, FULL>(a.stepdown_mask + g0, valid, sm);
+            st_u8<V, NTS, FULL>(a.elected + g0, valid, el);
+            st_i32<V, NTS, FULL>(a.max_term + g0, valid, mx);
+        }
+    }
+
+    if constexpr (DO_COMMIT) {
+        int32_t co[V];
+#pragma unroll
+        for (int k = 0; k < V; k++) {
+            co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
+            st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
+        }
+        if (in_range) st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
+    }
+    if (in_range && a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
+    return el_field;
+}
+
+template <int MMAX, int V, int WHAT, int FLAGS>
+__global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args a) {
+    const uint64_t g0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    uint32_t el_field;
+    // Every lane runs a body: the wave-wide ballots inside need all of them.
+    if (g0 + V <= a.G)
+        el_field = round_joint_body<MMAX, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, true);
+    else {
+        const bool in_range = g0 < a.G;
+        el_field = round_joint_body<MMAX, V, WHAT, FLAGS, false>(
+            a, in_range ? (uint32_t)g0 : 0u, in_range ? (int)(a.G - g0) : 0, in_range);
+    }
+    if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
+        if (a.elected_bits) pack_elected<V>(el_field, g0, a.G, a.elected_bits);
+    }
+}
+
+// raft.go:172-176 elementwise
+__global__ __launch_bounds__(kBlock) void rq_follower_clamp_kernel(
+        uint64_t count, const int32_t *lc, const int32_t *ci, const int32_t *ln,
+        int32_t *out, int vec_ok) {
+    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+    if (i0 >= count) return;
+    int32_t a[4], b[4], c[4], r[4];
+    const bool full = vec_ok && i0 + 4 <= count;
+    const int valid = full ? 4 : (int)min((uint64_t)4, count - i0);
+    if (full) {
+        ld_i32<4, false, true>(lc + i0, 4, a);
+        ld_i32<4, false, true>(ci + i0, 4, b);
+        ld_i32<4, false, true>(ln + i0, 4, c);
+    } else {
+        ld_i32<4, false, false>(lc + i0, valid, a);
+        ld_i32<4, false, false>(ci + i0, valid, b);
+        ld_i32<4, false, false>(ln + i0, valid, c);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) r[k] = a[k] > b[k] ? min(a[k], c[k]) : b[k];
+    if (full) st_i32<4, false, true>(out + i0, 4, r);
+    else st_i32<4, false, false>(out + i0, valid, r);
+}
+
+// ---------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------
+template <int N, int V, int WHAT, int FLAGS>
+hipError_t launch_fixed(const rq_round_args &a, hipStream_t s) {
+    const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
+    const uint32_t grid = (uint32_t)((threads + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((rq_round_fixed<N, V, WHAT, FLAGS>), dim3(grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int N, int V, int WHAT>
+hipError_t launch_fixed_flags(const rq_round_args &a, int flags, hipStream_t s) {
+    // the cache-policy builds exist for the fused round only
+    if constexpr (WHAT != (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) return launch_fixed<N, V, WHAT, 0>(a, s);
+    else
+    switch (flags & (RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE)) {
+    case 0: return launch_fixed<N, V, WHAT, 0>(a, s);
+    case RQ_VAR_NT_LOAD: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD>(a, s);
+    case RQ_VAR_NT_STORE: return launch_fixed<N, V, WHAT, RQ_VAR_NT_STORE>(a, s);
+    default: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE>(a, s);
+    }
+}
+
+template <int N, int WHAT>
+hipError_t launch_fixed_v(const rq_round_args &a, int v, int flags, hipStream_t s) {
+    switch (v) {
+    case 1: return launch_fixed_flags<N, 1, WHAT>(a, flags, s);
+    case 2: return launch_fixed_flags<N, 2, WHAT>(a, flags, s);
+    default: return launch_fixed_flags<N, 4, WHAT>(a, flags, s);
+    }
+}
+
+template <int N>
+hipError_t launch_fixed_what(const rq_round_args &a, int what, int v, int flags, hipStream_t s) {
+    switch (what) {
+    case RQ_WHAT_COMMIT: return launch_fixed_v<N, RQ_WHAT_COMMIT>(a, v, flags, s);
+    case RQ_WHAT_VOTE: return launch_fixed_v<N, RQ_WHAT_VOTE>(a, v, flags, s);
+    default: return launch_fixed_v<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, s);
+    }
+}
+
+template <int MMAX, int V, int WHAT>
+hipError_t launch_joint(const rq_round_args &a, hipStream_t s) {
+    const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
+    const uint32_t grid = (uint32_t)((threads + kBlock - 1) / kBlock);
+    hipLaunchKernelGGL((rq_round_joint<MMAX, V, WHAT, 0>), dim3(grid), dim3(kBlock), 0, s, a);
+    return hipGetLastError();
+}
+
+template <int MMAX, int WHAT>
+hipError_t launch_joint_v(const rq_round_args &a, int v, hipStream_t s) {
+    switch (v) {
+    case 1: return launch_joint<MMAX, 1, WHAT>(a, s);
+    default: return launch_joint<MMAX, 2, WHAT>(a, s);
+    }
+}
+
+template <int MMAX>
+hipError_t launch_joint_what(const rq_round_args &a, int what, int v, hipStream_t s) {
+    switch (what) {
+    case RQ_WHAT_COMMIT: return launch_joint_v<MMAX, RQ_WHAT_COMMIT>(a, v, s);
+    case RQ_WHAT_VOTE: return launch_joint_v<MMAX, RQ_WHAT_VOTE>(a, v, s);
+    default: return launch_joint_v<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, s);
+    }
+}
+
+inline bool aligned_to(const void *p, size_t a) {
+    return p == nullptr || (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0;
+}
+
+// Largest V in {4,2,1} not above `want` for which every plane row start
+// (base + p*ld) and every per-group array is aligned for a V-wide access.
+int pick_v(const rq_round_args &a, int want, int what) {
+    for (int v = want; v > 1; v >>= 1) {
+        bool ok = (a.ld % v) == 0;
+        if (what & RQ_WHAT_COMMIT)
+            ok = ok && aligned_to(a.match, 4 * v) && aligned_to(a.commit, 4 * v) &&
+                 aligned_to(a.leader_term, 4 * v) && aligned_to(a.log_off, 4 * v) &&
+                 aligned_to(a.commit_out, 4 * v);
+        if (what & RQ_WHAT_VOTE)
+            ok = ok && aligned_to(a.voter_term, 4 * v) && aligned_to(a.voted_for, 4 * v) &&
+                 aligned_to(a.last_log_term, 4 * v) && aligned_to(a.cand_term, 4 * v) &&
+                 aligned_to(a.cand_id, 4 * v) && aligned_to(a.voter_term_out, 4 * v) &&
+                 aligned_to(a.grant_mask, 2 * v) && aligned_to(a.stepdown_mask, 2 * v) &&
+                 aligned_to(a.elected, v) && aligned_to(a.max_term, 4 * v);
+        ok = ok && aligned_to(a.status_out, v) && aligned_to(a.old_mask, 2 * v) &&
+             aligned_to(a.new_mask, 2 * v);
+        if (ok) return v;
+    }
+    return 1;
+}
+
+}  // namespace
+
+hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint, int what,
+                           int variant, hipStream_t stream) {
+    if (a.G == 0) return hipSuccess;
+    if (a.G > 0x7FFFFFFFu || a.ld < a.G) return hipErrorInvalidValue;
+    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
+    const int flags = variant & ~RQ_VAR_V_MASK;
+    int want = variant & RQ_VAR_V_MASK;
+    if (want != 0 && want != 1 && want != 2 && want != 4) return hipErrorInvalidValue;
+
+    if (!joint && n >= 1 && n <= 9) {
+        if (want == 0) want = 4;
+        const int v = pick_v(a, want, what);
+        switch (n) {
+        case 1: return launch_fixed_what<1>(a, what, v, flags, stream);
+        case 2: return launch_fixed_what<2>(a, what, v, flags, stream);
+        case 3: return launch_fixed_what<3>(a, what, v, flags, stream);
+        case 4: return launch_fixed_what<4>(a, what, v, flags, stream);
+        case 5: return launch_fixed_what<5>(a, what, v, flags, stream);
+        case 6: return launch_fixed_what<6>(a, what, v, flags, stream);
+        case 7: return launch_fixed_what<7>(a, what, v, flags, stream);
+        case 8: return launch_fixed_what<8>(a, what, v, flags, stream);
+        default: return launch_fixed_what<9>(a, what, v, flags, stream);
+        }
+    }
+    // per-group membership, or a fixed size beyond the register networks
+    rq_round_args b = a;
+    if (!joint) { b.m = n; b.old_mask = nullptr; b.new_mask = nullptr; }
+    if (b.m < 1 || b.m > 16) return hipErrorInvalidValue;
+    if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
+    if (want == 0 || want > 2) want = 2;
+    const int v = pick_v(b, want, what);
+    if (b.m <= 8) return launch_joint_what<8>(b, what, v, stream);
+    return launch_joint_what<16>(b, what, v, stream);
+}
+
+hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,
+                                    const int32_t *commit, const int32_t *last_new_index,
+                                    int32_t *commit_out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    const int vec_ok = aligned_to(leader_commit, 16) && aligned_to(commit, 16) &&
+                       aligned_to(last_new_index, 16) && aligned_to(commit_out, 16);
+    const uint64_t threads = (count + 3) / 4;
+    const uint64_t grid = (threads + kBlock - 1) / kBlock;
+    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rq_follower_clamp_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, stream,
+                       count, leader_commit, commit, last_new_index, commit_out, vec_ok);
+    return hipGetLastError();
+}

@@ -1,0 +1,238 @@
+"""numpy-facing wrapper over the rq_* C-ABI (host-buffer entry points).
+
+Mirrors the batched driver a Go host would write around cgo: flat int32
+slot-major planes in, decision vectors out.  All arithmetic happens in
+librq.so's HIP kernels; this file only checks shapes and marshals pointers.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import RqError, i32p, u8p, u16p, u32p
+
+ST_LOG_OOB = 0x01
+ST_EMPTY_LOG = 0x02
+LOG_EMPTY = np.iinfo(np.int32).min
+MAX_SLOTS = 16
+
+
+def _plane(a, name):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if a.ndim != 2:
+        raise ValueError("%s must be a [slots][ld] int32 array" % name)
+    return a
+
+
+def _vec(a, dtype, name, G):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    if a.ndim != 1 or a.shape[0] < G:
+        raise ValueError("%s must be a 1-D %s array of at least %d" % (name, np.dtype(dtype).name, G))
+    return a
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class VoteResult:
+    __slots__ = ("voter_term", "grant_mask", "stepdown_mask", "elected", "max_term", "status")
+
+
+class RoundResult(VoteResult):
+    __slots__ = ("commit",)
+
+
+class QuorumEngine:
+    """One engine = one GPU, one stream (rq_engine_create .. rq_engine_destroy)."""
+
+    def __init__(self, max_groups, max_slots=5, max_log_terms=None, device=0):
+        self._l = _lib.lib()
+        if max_log_terms is None:
+            max_log_terms = 16 * max_groups
+        h = C.c_void_p()
+        rc = self._l.rq_engine_create(device, max_groups, max_slots, max_log_terms, C.byref(h))
+        if rc != 0:
+            raise RqError(rc, "rq_engine_create")
+        self._h = h
+        self.max_groups, self.max_slots, self.max_log_terms = max_groups, max_slots, max_log_terms
+
+    # -- lifetime ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._l.rq_engine_destroy(self._h)
+            self._h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _check(self, rc, where):
+        if rc != 0:
+            raise RqError(rc, where, self._l.rq_last_hip_error(self._h))
+
+    # -- helpers ----------------------------------------------------------
+    @staticmethod
+    def _commit_in(match, commit, leader_term, log_off, log_term, G):
+        match = _plane(match, "match")
+        n, ld = match.shape
+        G = ld if G is None else G
+        commit = _vec(commit, np.int32, "commit", G)
+        leader_term = _vec(leader_term, np.int32, "leader_term", G)
+        log_off = _vec(log_off, np.uint32, "log_off", G + 1)
+        log_term = np.ascontiguousarray(log_term, dtype=np.int32)
+        if log_term.size == 0:
+            log_term = np.zeros(1, np.int32)
+        return match, n, ld, G, commit, leader_term, log_off, log_term
+
+    @staticmethod
+    def _vote_in(voter_term, voted_for, last_log_term, cand_term, cand_id, G):
+        voter_term = _plane(voter_term, "voter_term")
+        n, ld = voter_term.shape
+        G = ld if G is None else G
+        voted_for = _plane(voted_for, "voted_for")
+        last_log_term = _plane(last_log_term, "voter_last_log_term")
+        if voted_for.shape != (n, ld) or last_log_term.shape != (n, ld):
+            raise ValueError("vote planes must share one [slots][ld] shape")
+        cand_term = _vec(cand_term, np.int32, "cand_term", G)
+        cand_id = _vec(cand_id, np.int32, "cand_id", G)
+        return voter_term, voted_for, last_log_term, n, ld, G, cand_term, cand_id
+
+    @staticmethod
+    def _vote_out(n, ld, G, voter_term):
+        r = {}
+        r["voter_term"] = voter_term.copy()  # non-member / padding lanes keep inputs
+        r["grant_mask"] = np.zeros(G, np.uint16)
+        r["stepdown_mask"] = np.zeros(G, np.uint16)
+        r["elected"] = np.zeros(G, np.uint8)
+        r["max_term"] = np.zeros(G, np.int32)
+        r["status"] = np.zeros(G, np.uint8)
+        return r
+
+    @staticmethod
+    def _pack_vote(res, o):
+        res.voter_term, res.grant_mask, res.stepdown_mask = o["voter_term"], o["grant_mask"], o["stepdown_mask"]
+        res.elected, res.max_term, res.status = o["elected"], o["max_term"], o["status"]
+        return res
+
+    @staticmethod
+    def _masks(old_mask, new_mask, G):
+        return _vec(old_mask, np.uint16, "old_mask", G), _vec(new_mask, np.uint16, "new_mask", G)
+
+    # -- entry points -------------------------------------------------------
+    def commit_advance(self, match, commit, leader_term, log_off, log_term, G=None,
+                       old_mask=None, new_mask=None):
+        match, n, ld, G, commit, leader_term, log_off, log_term = self._commit_in(
+            match, commit, leader_term, log_off, log_term, G)
+        out = np.zeros(G, np.int32)
+        st = np.zeros(G, np.uint8)
+        tail = (_p(match, i32p), _p(commit, i32p), _p(leader_term, i32p), _p(log_off, u32p),
+                _p(log_term, i32p), _p(out, i32p), _p(st, u8p))
+        if old_mask is None:
+            rc = self._l.rq_commit_advance(self._h, G, n, ld, *tail)
+            self._check(rc, "rq_commit_advance")
+        else:
+            om, nm = self._masks(old_mask, new_mask, G)
+            rc = self._l.rq_commit_advance_joint(self._h, G, n, ld, _p(om, u16p), _p(nm, u16p), *tail)
+            self._check(rc, "rq_commit_advance_joint")
+        return out, st
+
+    def vote_tally(self, voter_term, voted_for, last_log_term, cand_term, cand_id, G=None,
+                   old_mask=None, new_mask=None):
+        vt, vf, ll, n, ld, G, ct, ci = self._vote_in(voter_term, voted_for, last_log_term,
+                                                     cand_term, cand_id, G)
+        o = self._vote_out(n, ld, G, vt)
+        tail = (_p(vt, i32p), _p(vf, i32p), _p(ll, i32p), _p(ct, i32p), _p(ci, i32p),
+                _p(o["voter_term"], i32p), _p(o["grant_mask"], u16p), _p(o["stepdown_mask"], u16p),
+                _p(o["elected"], u8p), _p(o["max_term"], i32p), _p(o["status"], u8p))
+        if old_mask is None:
+            self._check(self._l.rq_vote_tally(self._h, G, n, ld, *tail), "rq_vote_tally")
+        else:
+            om, nm = self._masks(old_mask, new_mask, G)
+            self._check(self._l.rq_vote_tally_joint(self._h, G, n, ld, _p(om, u16p), _p(nm, u16p), *tail),
+                        "rq_vote_tally_joint")
+        return self._pack_vote(VoteResult(), o)
+
+    def fused_round(self, match, commit, leader_term, log_off, log_term,
+                    voter_term, voted_for, last_log_term, cand_term, cand_id, G=None,
+                    old_mask=None, new_mask=None):
+        match, n, ld, G, commit, leader_term, log_off, log_term = self._commit_in(
+            match, commit, leader_term, log_off, log_term, G)
+        vt, vf, ll, n2, ld2, _, ct, ci = self._vote_in(voter_term, voted_for, last_log_term,
+                                                       cand_term, cand_id, G)
+        if (n2, ld2) != (n, ld):
+            raise ValueError("commit and vote planes must share one [slots][ld] shape")
+        o = self._vote_out(n, ld, G, vt)
+        cout = np.zeros(G, np.int32)
+        tail = (_p(match, i32p), _p(commit, i32p), _p(leader_term, i32p), _p(log_off, u32p),
+                _p(log_term, i32p),
+                _p(vt, i32p), _p(vf, i32p), _p(ll, i32p), _p(ct, i32p), _p(ci, i32p),
+                _p(cout, i32p), _p(o["voter_term"], i32p), _p(o["grant_mask"], u16p),
+                _p(o["stepdown_mask"], u16p), _p(o["elected"], u8p), _p(o["max_term"], i32p),
+                _p(o["status"], u8p))
+        if old_mask is None:
+            self._check(self._l.rq_fused_round(self._h, G, n, ld, *tail), "rq_fused_round")
+        else:
+            om, nm = self._masks(old_mask, new_mask, G)
+            self._check(self._l.rq_fused_round_joint(self._h, G, n, ld, _p(om, u16p), _p(nm, u16p), *tail),
+                        "rq_fused_round_joint")
+        res = self._pack_vote(RoundResult(), o)
+        res.commit = cout
+        return res
+
+    def follower_clamp(self, leader_commit, commit, last_new_index):
+        lc = np.ascontiguousarray(leader_commit, dtype=np.int32).ravel()
+        ci = np.ascontiguousarray(commit, dtype=np.int32).ravel()
+        ln = np.ascontiguousarray(last_new_index, dtype=np.int32).ravel()
+        if not (lc.size == ci.size == ln.size):
+            raise ValueError("follower_clamp arrays must have equal length")
+        out = np.zeros(lc.size, np.int32)
+        self._check(self._l.rq_follower_clamp(self._h, lc.size, _p(lc, i32p), _p(ci, i32p),
+                                              _p(ln, i32p), _p(out, i32p)), "rq_follower_clamp")
+        return out
+
+    # -- device-resident trio ----------------------------------------------
+    def upload(self, match, commit, leader_term, log_off, log_term,
+               voter_term, voted_for, last_log_term, cand_term, cand_id, G=None):
+        match, n, ld, G, commit, leader_term, log_off, log_term = self._commit_in(
+            match, commit, leader_term, log_off, log_term, G)
+        vt, vf, ll, n2, ld2, _, ct, ci = self._vote_in(voter_term, voted_for, last_log_term,
+                                                       cand_term, cand_id, G)
+        if (n2, ld2) != (n, ld):
+            raise ValueError("commit and vote planes must share one [slots][ld] shape")
+        self._check(self._l.rq_upload(self._h, G, n, ld, _p(match, i32p), _p(commit, i32p),
+                                      _p(leader_term, i32p), _p(log_off, u32p), _p(log_term, i32p),
+                                      _p(vt, i32p), _p(vf, i32p), _p(ll, i32p), _p(ct, i32p),
+                                      _p(ci, i32p)), "rq_upload")
+        self._res = (G, n)
+
+    def step(self, rounds=1):
+        self._check(self._l.rq_step(self._h, rounds), "rq_step")
+
+    def download(self):
+        G, n = self._res
+        res = RoundResult()
+        res.commit = np.zeros(G, np.int32)
+        res.voter_term = np.zeros((n, G), np.int32)
+        res.grant_mask = np.zeros(G, np.uint16)
+        res.stepdown_mask = np.zeros(G, np.uint16)
+        res.elected = np.zeros(G, np.uint8)
+        res.max_term = np.zeros(G, np.int32)
+        res.status = np.zeros(G, np.uint8)
+        self._check(self._l.rq_download(self._h, _p(res.commit, i32p), _p(res.voter_term, i32p),
+                                        _p(res.grant_mask, u16p), _p(res.stepdown_mask, u16p),
+                                        _p(res.elected, u8p), _p(res.max_term, i32p),
+                                        _p(res.status, u8p)), "rq_download")
+        return res

@@ -1,0 +1,244 @@
+"""Deterministic synthetic Raft-group batches (counter-based splitmix64).
+
+Every value is a pure function of (seed, field id, flat index), so any slice
+of a batch can be regenerated anywhere (host language, rank, test) without
+shipping fixtures.  Layout matches the rq_* C-ABI: slot-major int32 planes
+field[p, g], CSR leader logs (log_off uint32 [G+1], log_term int32 arena).
+"""
+import numpy as np
+
+M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+DEFAULT_SEED = 0x5EED0001
+LOG_EMPTY = np.iinfo(np.int32).min
+
+# field ids
+F_LOGLEN, F_LOGT, F_MATCH, F_COMMIT, F_LTERM, F_CTERM, F_CID, F_VTERM, F_VFOR, F_VLLT, \
+    F_NSLOT, F_JOINT, F_AUX, F_AUX2 = range(1, 15)
+
+
+def splitmix64(x):
+    """One splitmix64 output for each uint64 counter in x."""
+    with np.errstate(over="ignore"):
+        z = (np.asarray(x, dtype=np.uint64) + np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def draw(seed, field, idx):
+    """uint64 draws for flat indices idx (array) of one field."""
+    with np.errstate(over="ignore"):
+        key = splitmix64(np.uint64(seed) ^ (np.uint64(field) * np.uint64(0xD1B54A32D192ED03)))
+        return splitmix64(key ^ splitmix64(np.asarray(idx, dtype=np.uint64)))
+
+
+def _below(seed, field, idx, k):
+    """Integer draws in [0, k) (k scalar or array, k >= 1) as int64."""
+    return (draw(seed, field, idx) % np.asarray(k, dtype=np.uint64)).astype(np.int64)
+
+
+def _unit(seed, field, idx):
+    """Uniform doubles in [0, 1)."""
+    return (draw(seed, field, idx) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def quorum_index(match, members=None):
+    """ascending_sorted(match over slots)[(n-1)//2] per group (numpy; used only
+    to SHAPE the synthetic distributions, e.g. 'about half the groups advance')."""
+    m = np.sort(match.astype(np.int64), axis=0)
+    return m[(match.shape[0] - 1) // 2]
+
+
+class Batch(dict):
+    """dict of numpy arrays with attribute access; keys follow the C-ABI names."""
+    __getattr__ = dict.__getitem__
+
+    def commit_args(self):
+        return (self.match, self.commit, self.leader_term, self.log_off, self.log_term)
+
+    def vote_args(self):
+        return (self.voter_term, self.voted_for, self.last_log_term, self.cand_term, self.cand_id)
+
+    def fused_args(self):
+        return self.commit_args() + self.vote_args()
+
+
+def _csr(lens):
+    off = np.zeros(lens.size + 1, np.uint64)
+    np.cumsum(lens, out=off[1:])
+    if off[-1] > 0xFFFFFFFF:
+        raise ValueError("log arena exceeds uint32 offsets")
+    return off.astype(np.uint32)
+
+
+def _monotone_log(seed, G, lens, off, tmax):
+    """term_at(i) = 1 + floor(i * T_g / len_g): non-decreasing terms 1..T_g."""
+    total = int(off[-1])
+    grp = np.repeat(np.arange(G, dtype=np.int64), lens)
+    pos = np.arange(total, dtype=np.int64) - off[:-1].astype(np.int64)[grp]
+    T = 1 + _below(seed, F_LOGT, np.arange(G), tmax)
+    return (1 + (pos * T[grp]) // lens[grp]).astype(np.int32), T
+
+
+def _vote_side(seed, G, n, ld, base_term):
+    """candTerm = t; voterTerm in {t-1: 60%, t: 30%, t+1: 10%}; votedFor in
+    {-1: 50%, candId: 25%, other: 25%}; lastLogTerm ~ U[0, t+1]; slot 0 is the
+    candidate itself (term t, voted for itself, log not ahead of t)."""
+    g = np.arange(G, dtype=np.int64)
+    t = base_term.astype(np.int64)
+    cand_id = _below(seed, F_CID, g, n)
+    vt = np.zeros((n, ld), np.int32)
+    vf = np.zeros((n, ld), np.int32)
+    ll = np.zeros((n, ld), np.int32)
+    for p in range(n):
+        idx = p * G + g
+        u = _unit(seed, F_VTERM, idx)
+        vt[p, :G] = t + np.where(u < 0.6, -1, np.where(u < 0.9, 0, 1))
+        u = _unit(seed, F_VFOR, idx)
+        other = (cand_id + 1 + _below(seed, F_AUX, idx, max(n - 1, 1))) % max(n, 1)
+        vf[p, :G] = np.where(u < 0.5, -1, np.where(u < 0.75, cand_id, other))
+        ll[p, :G] = _below(seed, F_VLLT, idx, t + 2)
+    vt[0, :G] = t
+    vf[0, :G] = cand_id
+    ll[0, :G] = np.minimum(ll[0, :G], t)
+    ct = np.zeros(ld, np.int32); ct[:G] = t
+    ci = np.zeros(ld, np.int32); ci[:G] = cand_id
+    return vt, vf, ll, ct[:G].copy(), ci[:G].copy()
+
+
+def _commit_side(seed, G, n, ld, lens, off, log_term, members=None):
+    """match[p] ~ U[0, len); about half the groups have N > commit and about
+    70% of those pass the log[N].term == leaderTerm gate."""
+    g = np.arange(G, dtype=np.int64)
+    match = np.zeros((n, ld), np.int32)
+    for p in range(n):
+        match[p, :G] = _below(seed, F_MATCH, p * G + g, lens)
+    if members is None:
+        N = quorum_index(match[:, :G])
+    else:
+        N = members(match[:, :G])
+    adv = _unit(seed, F_COMMIT, g) < 0.5
+    below = _below(seed, F_AUX2, g, np.maximum(N, 1))           # in [0, N)
+    commit = np.where(adv & (N > 0), below, N + _below(seed, F_AUX2, g, 3))
+    Nc = np.clip(N, 0, np.maximum(lens - 1, 0))
+    t_at = log_term[off[:-1].astype(np.int64) + Nc].astype(np.int64) if log_term.size else np.zeros(G, np.int64)
+    gate = _unit(seed, F_LTERM, g) < 0.7
+    leader_term = np.where(gate, t_at, t_at + 1)
+    return match, commit.astype(np.int32), leader_term.astype(np.int32)
+
+
+def gen_fused(G, n=5, seed=DEFAULT_SEED, ld=None, max_len=16, tmax=8):
+    """1M x 5 style batch (the headline configuration at G = 1 << 20):
+    log lengths ~ U[1, max_len]."""
+    ld = G if ld is None else ld
+    g = np.arange(G, dtype=np.int64)
+    lens = 1 + _below(seed, F_LOGLEN, g, max_len)
+    off = _csr(lens)
+    log_term, T = _monotone_log(seed, G, lens, off, tmax)
+    match, commit, leader_term = _commit_side(seed, G, n, ld, lens, off, log_term)
+    vt, vf, ll, ct, ci = _vote_side(seed, G, n, ld, 2 + T)
+    return Batch(G=G, n=n, ld=ld, match=match, commit=commit, leader_term=leader_term,
+                 log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
+                 last_log_term=ll, cand_term=ct, cand_id=ci)
+
+
+def gen_commit_small(G=10000, n=3, seed=DEFAULT_SEED, log_len=32):
+    """10k x 3 commit-only configuration: fixed 32-entry logs, monotone terms
+    1 + floor(i*T/32) with T = leaderTerm in [1, 8], match in [0, 31]."""
+    b = gen_fused(G, n, seed, max_len=1)  # vote side unused but kept complete
+    g = np.arange(G, dtype=np.int64)
+    lens = np.full(G, log_len, np.int64)
+    off = _csr(lens)
+    log_term, T = _monotone_log(seed, G, lens, off, 8)
+    match, commit, _ = _commit_side(seed, G, n, G, lens, off, log_term)
+    b.update(match=match, commit=commit, leader_term=T.astype(np.int32), log_off=off, log_term=log_term)
+    return b
+
+
+def _zipf_lens(seed, G, s=1.2, lo=1, hi=4096):
+    """Zipf(s) lengths clipped to [lo, hi] by inverse-CDF on a finite support."""
+    k = np.arange(lo, hi + 1, dtype=np.float64)
+    cdf = np.cumsum(k ** (-s)); cdf /= cdf[-1]
+    u = _unit(seed, F_LOGLEN, np.arange(G))
+    return (lo + np.searchsorted(cdf, u, side="left")).astype(np.int64)
+
+
+def masked_quorum_index(match, mask):
+    """Quorum index over the member subset given by per-group bit masks."""
+    m, G = match.shape
+    member = ((mask[None, :].astype(np.int64) >> np.arange(m)[:, None]) & 1).astype(bool)
+    big = np.iinfo(np.int64).max
+    vals = np.where(member, match.astype(np.int64), big)   # non-members sort last
+    s = np.sort(vals, axis=0)
+    cnt = member.sum(axis=0)
+    return s[np.maximum(cnt - 1, 0) // 2, np.arange(G)]
+
+
+def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi=9):
+    """Mixed 3-9 slot clusters, a fraction in joint consensus (old and new
+    configurations overlapping in at least one slot, all within 16 slots),
+    Zipf(1.2) log lengths clipped to [1, 4096].  bucketed=True orders groups by
+    highest member slot so that waves are homogeneous (a host-side layout
+    choice; results do not depend on it)."""
+    m = 16
+    g = np.arange(G, dtype=np.int64)
+    n_old = n_lo + _below(seed, F_NSLOT, g, n_hi - n_lo + 1)
+    is_joint = _unit(seed, F_JOINT, g) < joint_frac
+    n_new = n_lo + _below(seed, F_NSLOT, G + g, n_hi - n_lo + 1)
+    shift = 1 + _below(seed, F_AUX, 7 * G + g, np.maximum(n_old - 1, 1))   # 1..n_old-1: overlap >= 1
+    n_new = np.minimum(n_new, m - shift)
+    old_mask = (1 << n_old) - 1
+    new_mask = np.where(is_joint, ((1 << n_new) - 1) << shift, old_mask)
+    if bucketed:
+        top = np.floor(np.log2((old_mask | new_mask).astype(np.float64))).astype(np.int64)
+        order = np.argsort(top, kind="stable")
+        old_mask, new_mask = old_mask[order], new_mask[order]
+    old_mask = old_mask.astype(np.uint16); new_mask = new_mask.astype(np.uint16)
+    lens = _zipf_lens(seed, G)
+    off = _csr(lens)
+    log_term, T = _monotone_log(seed, G, lens, off, 8)
+
+    def members(match):
+        return np.minimum(masked_quorum_index(match, old_mask), masked_quorum_index(match, new_mask))
+
+    match, commit, leader_term = _commit_side(seed, G, m, G, lens, off, log_term, members)
+    vt, vf, ll, ct, ci = _vote_side(seed, G, m, G, 2 + T)
+    return Batch(G=G, n=m, ld=G, match=match, commit=commit, leader_term=leader_term,
+                 log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
+                 last_log_term=ll, cand_term=ct, cand_id=ci, old_mask=old_mask, new_mask=new_mask)
+
+
+def gen_adversarial(G, n, seed=DEFAULT_SEED, ld=None):
+    """Edge-heavy batch for parity tests: empty leader logs, N outside the log,
+    negative and extreme int32 values, empty voter logs, candidate id -1."""
+    ld = G if ld is None else ld
+    g = np.arange(G, dtype=np.int64)
+    lens = _below(seed, F_LOGLEN, g, 6)                      # 0..5, empty logs included
+    off = _csr(lens)
+    total = int(off[-1])
+    log_term = (_below(seed, F_LOGT, np.arange(total), 4) + 1).astype(np.int32)
+    ext = np.array([np.iinfo(np.int32).min, -1, 0, 1, 2, 3, 5, np.iinfo(np.int32).max], np.int64)
+    match = np.zeros((n, ld), np.int32)
+    for p in range(n):
+        idx = p * G + g
+        small = _below(seed, F_MATCH, idx, 8) - 1               # -1..6: often >= len
+        pick = _unit(seed, F_AUX, idx) < 0.05
+        match[p, :G] = np.where(pick, ext[_below(seed, F_AUX2, idx, ext.size)], small)
+    commit = (_below(seed, F_COMMIT, g, 7) - 2).astype(np.int32)
+    leader_term = (_below(seed, F_LTERM, g, 4) + 1).astype(np.int32)
+    vt = np.zeros((n, ld), np.int32); vf = np.zeros((n, ld), np.int32); ll = np.zeros((n, ld), np.int32)
+    for p in range(n):
+        idx = p * G + g
+        vt[p, :G] = np.where(_unit(seed, F_VTERM, idx) < 0.03,
+                             ext[_below(seed, F_AUX, 3 * n * G + idx, ext.size)],
+                             _below(seed, F_VTERM, n * G + idx, 5))
+        vf[p, :G] = _below(seed, F_VFOR, idx, n + 2) - 2       # -2..n-1, -1 is null
+        u = _unit(seed, F_VLLT, idx)
+        ll[p, :G] = np.where(u < 0.08, LOG_EMPTY, _below(seed, F_VLLT, n * G + idx, 6))
+    cand_term = np.where(_unit(seed, F_CTERM, g) < 0.03,
+                         ext[_below(seed, F_CTERM, G + g, ext.size)],
+                         _below(seed, F_CTERM, 2 * G + g, 5)).astype(np.int32)
+    cand_id = (_below(seed, F_CID, g, n + 1) - 1).astype(np.int32)   # -1 collides with null
+    return Batch(G=G, n=n, ld=ld, match=match, commit=commit, leader_term=leader_term,
+                 log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
+                 last_log_term=ll, cand_term=cand_term, cand_id=cand_id)

@@ -1,0 +1,170 @@
+"""ctypes binding of oracle/librq_oracle.so -- the CPU restatement of raft.go.
+
+Test infrastructure only: tests, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this; nothing under raft_amd/ does.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "oracle", "librq_oracle.so")
+
+i32p = C.POINTER(C.c_int32); u32p = C.POINTER(C.c_uint32)
+u16p = C.POINTER(C.c_uint16); u8p = C.POINTER(C.c_uint8)
+i64p = C.POINTER(C.c_int64)
+u32 = C.c_uint32
+
+
+class Entry(C.Structure):           # rf_entry  (raft.go:71-75)
+    _fields_ = [("command", C.c_char_p), ("index", C.c_int64), ("term_num", C.c_int64)]
+
+
+class Node(C.Structure):            # rf_node   (raft.go:15-69)
+    pass
+
+
+Node._fields_ = [
+    ("id", C.c_int64), ("node_type", C.c_int64), ("state_machine", C.c_void_p),
+    ("peers", C.POINTER(C.POINTER(Node))), ("n_peers", C.c_int64),
+    ("current_term", C.c_int64), ("voted_for", C.c_int64),
+    ("log", C.POINTER(Entry)), ("log_len", C.c_int64), ("log_cap", C.c_int64),
+    ("commit_index", C.c_int64), ("last_applied", C.c_int64),
+    ("next_index", i64p), ("match_index", i64p),
+]
+NodeP = C.POINTER(Node)
+LEADER, FOLLOWER, CANDIDATE = 0, 1, 2
+OK, PANIC_INDEX = 0, 1
+ST_LOG_OOB, ST_EMPTY_LOG = 1, 2
+
+_l = None
+
+
+def lib():
+    global _l
+    if _l is None:
+        if not os.path.exists(PATH):
+            raise ImportError("oracle/librq_oracle.so not built; run `make`")
+        l = C.CDLL(PATH)
+        l.rf_new_node.argtypes = [C.c_int64, C.POINTER(NodeP), C.c_int64, C.c_void_p]
+        l.rf_new_node.restype = NodeP
+        l.rf_free_cluster.argtypes = [NodeP]; l.rf_free_cluster.restype = None
+        for f in ("rf_become_leader", "rf_become_follower", "rf_become_candidate"):
+            getattr(l, f).argtypes = [NodeP]; getattr(l, f).restype = None
+        l.rf_append_entries_rpc.argtypes = [NodeP, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                            C.POINTER(Entry), C.c_int64, C.c_int64, i64p,
+                                            C.POINTER(C.c_int)]
+        l.rf_request_vote_rpc.argtypes = [NodeP, C.c_int64, C.c_int64, C.c_int64, C.c_int64, i64p,
+                                          C.POINTER(C.c_int)]
+        l.rf_test_to_abdicate_leadership.argtypes = [NodeP, C.c_int64]
+        l.rf_test_to_abdicate_leadership.restype = None
+        l.rf_min_int.argtypes = [C.c_int64, C.c_int64]; l.rf_min_int.restype = C.c_int64
+        l.rf_last_entry.argtypes = [C.POINTER(Entry), C.c_int64, C.POINTER(Entry)]
+        l.rf_log_append.argtypes = [NodeP, C.POINTER(Entry), C.c_int64]; l.rf_log_append.restype = None
+        l.rf_quorum_match_index.argtypes = [i64p, C.c_int64]; l.rf_quorum_match_index.restype = C.c_int64
+        l.rf_leader_advance_commit.argtypes = [NodeP]
+        l.orc_commit_advance.argtypes = [u32, u32, u32, i32p, i32p, i32p, u32p, i32p, i32p, u8p]
+        l.orc_vote_tally.argtypes = [u32, u32, u32, i32p, i32p, i32p, i32p, i32p, i32p, u16p, u16p,
+                                     u8p, i32p, u8p]
+        l.orc_commit_advance_joint.argtypes = [u32, u32, u32, u16p, u16p, i32p, i32p, i32p, u32p,
+                                               i32p, i32p, u8p]
+        l.orc_vote_tally_joint.argtypes = [u32, u32, u32, u16p, u16p, i32p, i32p, i32p, i32p, i32p,
+                                           i32p, u16p, u16p, u8p, i32p, u8p]
+        l.orc_follower_clamp.argtypes = [C.c_uint64, i32p, i32p, i32p, i32p]
+        l.orc_append_check.argtypes = [u32, u32, u32, i32p, i32p, i32p, i32p, u32p, i32p, i32p,
+                                       u16p, u16p, u8p]
+        l.orc_bench_build.argtypes = [u32, u32, u32, i32p, i32p, i32p, u32p, i32p, i32p, i32p, i32p,
+                                      i32p, i32p]
+        l.orc_bench_build.restype = C.c_void_p
+        l.orc_bench_run.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_uint64)]
+        l.orc_bench_run.restype = C.c_double
+        l.orc_bench_free.argtypes = [C.c_void_p]; l.orc_bench_free.restype = None
+        _l = l
+    return _l
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t)
+
+
+class Result(dict):
+    __getattr__ = dict.__getitem__
+
+
+def commit_advance(match, commit, leader_term, log_off, log_term, G=None, old_mask=None, new_mask=None):
+    match = _c(match, np.int32); n, ld = match.shape; G = ld if G is None else G
+    commit = _c(commit, np.int32); leader_term = _c(leader_term, np.int32)
+    log_off = _c(log_off, np.uint32); log_term = _c(log_term, np.int32)
+    if log_term.size == 0:
+        log_term = np.zeros(1, np.int32)
+    out = np.zeros(G, np.int32); st = np.zeros(G, np.uint8)
+    tail = (_p(match, i32p), _p(commit, i32p), _p(leader_term, i32p), _p(log_off, u32p),
+            _p(log_term, i32p), _p(out, i32p), _p(st, u8p))
+    if old_mask is None:
+        rc = lib().orc_commit_advance(G, n, ld, *tail)
+    else:
+        om = _c(old_mask, np.uint16); nm = _c(new_mask, np.uint16)
+        rc = lib().orc_commit_advance_joint(G, n, ld, _p(om, u16p), _p(nm, u16p), *tail)
+    assert rc == 0, rc
+    return out, st
+
+
+def vote_tally(voter_term, voted_for, last_log_term, cand_term, cand_id, G=None, old_mask=None, new_mask=None):
+    vt = _c(voter_term, np.int32); n, ld = vt.shape; G = ld if G is None else G
+    vf = _c(voted_for, np.int32); ll = _c(last_log_term, np.int32)
+    ct = _c(cand_term, np.int32); ci = _c(cand_id, np.int32)
+    r = Result(voter_term=vt.copy(), grant_mask=np.zeros(G, np.uint16), stepdown_mask=np.zeros(G, np.uint16),
+               elected=np.zeros(G, np.uint8), max_term=np.zeros(G, np.int32), status=np.zeros(G, np.uint8))
+    tail = (_p(vt, i32p), _p(vf, i32p), _p(ll, i32p), _p(ct, i32p), _p(ci, i32p),
+            _p(r.voter_term, i32p), _p(r.grant_mask, u16p), _p(r.stepdown_mask, u16p),
+            _p(r.elected, u8p), _p(r.max_term, i32p), _p(r.status, u8p))
+    if old_mask is None:
+        rc = lib().orc_vote_tally(G, n, ld, *tail)
+    else:
+        om = _c(old_mask, np.uint16); nm = _c(new_mask, np.uint16)
+        rc = lib().orc_vote_tally_joint(G, n, ld, _p(om, u16p), _p(nm, u16p), *tail)
+    assert rc == 0, rc
+    return r
+
+
+def fused_round(match, commit, leader_term, log_off, log_term, voter_term, voted_for, last_log_term,
+                cand_term, cand_id, G=None, old_mask=None, new_mask=None):
+    """The oracle has no fused form: a fused round IS the two decisions side by side."""
+    c, st_c = commit_advance(match, commit, leader_term, log_off, log_term, G, old_mask, new_mask)
+    r = vote_tally(voter_term, voted_for, last_log_term, cand_term, cand_id, G, old_mask, new_mask)
+    r["commit"] = c
+    r["status"] = r["status"] | st_c
+    return r
+
+
+def follower_clamp(leader_commit, commit, last_new_index):
+    lc = _c(leader_commit, np.int32).ravel(); ci = _c(commit, np.int32).ravel()
+    ln = _c(last_new_index, np.int32).ravel()
+    out = np.zeros(lc.size, np.int32)
+    assert lib().orc_follower_clamp(lc.size, _p(lc, i32p), _p(ci, i32p), _p(ln, i32p), _p(out, i32p)) == 0
+    return out
+
+
+def cpu_baseline(batch, passes, threads):
+    """Times the reference-shaped heap-object path (one RequestVoteRPC-shaped
+    call per voter, one sort per leader) on `threads` host threads.
+    Returns (seconds, checksum)."""
+    b = batch
+    arrs = [_c(b["match"], np.int32), _c(b["commit"], np.int32), _c(b["leader_term"], np.int32),
+            _c(b["log_off"], np.uint32), _c(b["log_term"], np.int32), _c(b["voter_term"], np.int32),
+            _c(b["voted_for"], np.int32), _c(b["last_log_term"], np.int32), _c(b["cand_term"], np.int32),
+            _c(b["cand_id"], np.int32)]
+    types = [i32p, i32p, i32p, u32p, i32p, i32p, i32p, i32p, i32p, i32p]
+    n, ld = arrs[0].shape
+    h = lib().orc_bench_build(b["G"], n, ld, *[_p(a, t) for a, t in zip(arrs, types)])
+    try:
+        cs = C.c_uint64(0)
+        sec = lib().orc_bench_run(h, passes, threads, C.byref(cs))
+    finally:
+        lib().orc_bench_free(h)
+    return sec, cs.value

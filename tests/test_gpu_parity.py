@@ -1,0 +1,307 @@
+"""GPU parity: the HIP kernels, called through the rq_* C-ABI, against the CPU
+oracle (C restatement of raft.go) on identical inputs.  Integer work: every
+comparison is bit-exact (np.array_equal), no tolerances anywhere.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from raft_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")))
+VOTE_FIELDS = ("grant_mask", "stepdown_mask", "elected", "max_term", "status")
+
+
+def assert_vote_equal(got, exp, G, members=None):
+    for f in VOTE_FIELDS:
+        assert np.array_equal(getattr(got, f)[:G], exp[f][:G]), f
+    gv, ev = got.voter_term[:, :G], exp["voter_term"][:, :G]
+    if members is None:
+        assert np.array_equal(gv, ev), "voter_term"
+    else:
+        assert np.array_equal(gv[members], ev[members]), "voter_term(members)"
+
+
+def member_matrix(b):
+    mem = (b.old_mask | b.new_mask).astype(np.int64)
+    return ((mem[None, :] >> np.arange(b.n)[:, None]) & 1).astype(bool)
+
+
+# ---------------------------------------------------------------------------
+# known-answer vectors through the C-ABI
+# ---------------------------------------------------------------------------
+def test_vote_kats(engine):
+    ks = KATS["vote"]
+    vt = np.array([[k["voter"]["cur"] for k in ks]], np.int32)
+    vf = np.array([[k["voter"]["voted_for"] for k in ks]], np.int32)
+    ll = np.array([[k["voter"]["last_log_term"] for k in ks]], np.int32)
+    r = engine.vote_tally(vt, vf, ll, [k["req"]["term"] for k in ks], [k["req"]["cand"] for k in ks])
+    for g, k in enumerate(ks):
+        e = k["expect"]
+        assert r.voter_term[0, g] == e["cur"], k["id"]
+        assert r.max_term[g] == e["term_result"], k["id"]
+        assert bool(r.grant_mask[g] & 1) == e["grant"], k["id"]
+        # role' = Follower exactly when raft.go:219 fired
+        became_follower = k["req"]["term"] > k["voter"]["cur"]
+        assert bool(r.stepdown_mask[g] & 1) == became_follower, k["id"]
+        assert (e["role"] == 1) if became_follower else (e["role"] == k["voter"]["role"]), k["id"]
+
+
+def test_empty_voter_log_kats(engine):
+    for k in KATS["vote_empty_log"]:
+        v = k["voter"]
+        r = engine.vote_tally([[v["cur"]]], [[v["voted_for"]]], [[synth.LOG_EMPTY]],
+                              [k["req"]["term"]], [k["req"]["cand"]])
+        assert bool(r.status[0] & 2) == k["expect"]["panic"], k["id"]
+        assert r.voter_term[0, 0] == k["expect"]["cur"], k["id"]
+        assert not r.grant_mask[0], k["id"]
+
+
+def test_commit_and_quorum_kats(engine):
+    for k in KATS["commit"]:
+        n = len(k["match"])
+        match = np.array(k["match"], np.int32).reshape(n, 1)
+        out, st = engine.commit_advance(match, [k["commit"]], [k["leader_term"]],
+                                        [0, len(k["log_terms"])], np.array(k["log_terms"], np.int32))
+        assert out[0] == k["expect"], k
+        assert bool(st[0] & 1) == k["oob"], k
+    for k in KATS["quorum"]:      # identity log: term_at(N) == 1 everywhere, commit = -1 -> commit' = N
+        n = len(k["match"])
+        match = np.array(k["match"], np.int32).reshape(n, 1)
+        out, st = engine.commit_advance(match, [-1], [1], [0, 16], np.ones(16, np.int32))
+        assert out[0] == k["expect"] and st[0] == 0, k
+
+
+def test_tally_kats(engine):
+    for k in KATS["tally"]:
+        vt = np.array([[v["cur"]] for v in k["voters"]], np.int32)
+        vf = np.array([[v["voted_for"]] for v in k["voters"]], np.int32)
+        ll = np.array([[v["last_log_term"]] for v in k["voters"]], np.int32)
+        r = engine.vote_tally(vt, vf, ll, [k["term"]], [k["cand"]])
+        assert bin(r.grant_mask[0]).count("1") == k["expect"]["votes"], k
+        assert bool(r.elected[0]) == k["expect"]["elected"], k
+        assert r.max_term[0] == k["expect"]["max_term"], k
+
+
+def test_follower_clamp(engine):
+    ks = KATS["clamp"]
+    out = engine.follower_clamp([k["leader_commit"] for k in ks], [k["commit"] for k in ks],
+                                [k["last_new_index"] for k in ks])
+    assert out.tolist() == [k["expect"] for k in ks]
+    rng = np.random.default_rng(3)
+    for count in (1, 3, 4, 5, 1023, 100003):
+        lc, ci, ln = (rng.integers(-5, 50, count).astype(np.int32) for _ in range(3))
+        assert np.array_equal(engine.follower_clamp(lc, ci, ln), o.follower_clamp(lc, ci, ln))
+
+
+# ---------------------------------------------------------------------------
+# seeded batches: every cluster size, ragged group counts, padded strides
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("n", list(range(1, 10)) + [10, 13, 16])
+def test_fused_every_cluster_size(engine, n):
+    for G, ld in ((1, 1), (63, 63), (64, 64), (65, 68), (1000, 1000), (4099, 4352), (10000, 10000)):
+        for gen in (synth.gen_fused, synth.gen_adversarial):
+            b = gen(G, n, seed=1000 * n + G, ld=ld)
+            got = engine.fused_round(*b.fused_args(), G=G)
+            exp = o.fused_round(*b.fused_args(), G=G)
+            assert np.array_equal(got.commit, exp.commit), (n, G, gen.__name__)
+            assert_vote_equal(got, exp, G)
+
+
+@pytest.mark.parametrize("n", [3, 5, 7])
+def test_separate_kernels_match_fused(engine, n):
+    b = synth.gen_adversarial(30011, n, seed=77)
+    c, st = engine.commit_advance(*b.commit_args())
+    ec, est = o.commit_advance(*b.commit_args())
+    assert np.array_equal(c, ec) and np.array_equal(st, est)
+    v = engine.vote_tally(*b.vote_args())
+    assert_vote_equal(v, o.vote_tally(*b.vote_args()), b.G)
+
+
+def test_commit_only_10k_by_3(engine):
+    b = synth.gen_commit_small()            # 10k groups x 3 peers, 32-entry logs
+    c, st = engine.commit_advance(*b.commit_args())
+    ec, est = o.commit_advance(*b.commit_args())
+    assert np.array_equal(c, ec) and np.array_equal(st, est)
+    assert 0.05 < (c != b.commit).mean() < 0.95
+
+
+def test_empty_batch_and_errors(engine):
+    from raft_amd import RqError
+    z2 = np.zeros((5, 0), np.int32); z1 = np.zeros(0, np.int32)
+    r = engine.fused_round(z2, z1, z1, np.zeros(1, np.uint32), z1, z2, z2, z2, z1, z1)
+    assert r.commit.size == 0 and r.elected.size == 0
+    b = synth.gen_fused(8, 5)
+    with pytest.raises(RqError) as ei:      # log offsets must be monotone
+        bad = b.log_off.copy(); bad[3] = bad[4] + 1
+        engine.commit_advance(b.match, b.commit, b.leader_term, bad, b.log_term)
+    assert ei.value.code == -1
+    with pytest.raises(RqError) as ei:      # more slots than the ABI allows
+        engine.vote_tally(np.zeros((17, 8), np.int32), np.zeros((17, 8), np.int32),
+                          np.zeros((17, 8), np.int32), b.cand_term, b.cand_id)
+    assert ei.value.code == -1
+    with pytest.raises(RqError) as ei:      # empty configuration mask
+        engine.commit_advance(*b.commit_args(), old_mask=np.zeros(8, np.uint16), new_mask=np.full(8, 3, np.uint16))
+    assert ei.value.code == -7
+
+
+# ---------------------------------------------------------------------------
+# joint consensus / mixed cluster sizes
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("bucketed", [True, False])
+def test_mixed_sizes_and_joint_consensus(engine, bucketed):
+    for G in (1, 65, 5000, 40001):
+        b = synth.gen_mixed(G, seed=G, bucketed=bucketed)
+        got = engine.fused_round(*b.fused_args(), old_mask=b.old_mask, new_mask=b.new_mask)
+        exp = o.fused_round(*b.fused_args(), old_mask=b.old_mask, new_mask=b.new_mask)
+        assert np.array_equal(got.commit, exp.commit)
+        assert_vote_equal(got, exp, G, member_matrix(b))
+
+
+def test_joint_with_equal_masks_equals_simple(engine):
+    for n in (3, 5, 8):
+        b = synth.gen_adversarial(3001, n, seed=5 + n)
+        full = np.full(b.G, (1 << n) - 1, np.uint16)
+        got = engine.fused_round(*b.fused_args(), old_mask=full, new_mask=full)
+        exp = o.fused_round(*b.fused_args())
+        assert np.array_equal(got.commit, exp.commit)
+        assert_vote_equal(got, exp, b.G)
+
+
+def test_joint_random_masks_adversarial(engine):
+    rng = np.random.default_rng(11)
+    for m in (2, 5, 8, 9, 16):
+        G = 6007
+        b = synth.gen_adversarial(G, m, seed=300 + m)
+        lim = (1 << m) - 1
+        om = rng.integers(1, lim + 1, G).astype(np.uint16)
+        nm = rng.integers(1, lim + 1, G).astype(np.uint16)
+        b["old_mask"], b["new_mask"] = om, nm
+        got = engine.fused_round(*b.fused_args(), old_mask=om, new_mask=nm)
+        exp = o.fused_round(*b.fused_args(), old_mask=om, new_mask=nm)
+        assert np.array_equal(got.commit, exp.commit), m
+        assert_vote_equal(got, exp, G, member_matrix(b))
+        c, st = engine.commit_advance(*b.commit_args(), old_mask=om, new_mask=nm)
+        ec, est = o.commit_advance(*b.commit_args(), old_mask=om, new_mask=nm)
+        assert np.array_equal(c, ec) and np.array_equal(st, est)
+        v = engine.vote_tally(*b.vote_args(), old_mask=om, new_mask=nm)
+        assert_vote_equal(v, o.vote_tally(*b.vote_args(), old_mask=om, new_mask=nm), G, member_matrix(b))
+
+
+# ---------------------------------------------------------------------------
+# device-pointer launches: every kernel build, in-place update, bit summary
+# ---------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dev():
+    from raft_amd.device import DeviceEngine
+    d = DeviceEngine(0)
+    yield d
+    d.close()
+
+
+def _check_dev(res, exp, G, members=None):
+    assert np.array_equal(res["commit"], exp["commit"])
+    for f in VOTE_FIELDS:
+        assert np.array_equal(res[f], exp[f]), f
+    gv, ev = res["voter_term"][:, :G], exp["voter_term"][:, :G]
+    if members is None:
+        assert np.array_equal(gv, ev)
+    else:
+        assert np.array_equal(gv[members], ev[members])
+    bits = np.unpackbits(res["elected_bits"].view(np.uint8), bitorder="little")[:G]
+    assert np.array_equal(bits, exp["elected"]), "elected_bits"
+    assert not np.unpackbits(res["elected_bits"].view(np.uint8), bitorder="little")[G:].any()
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 0x14, 0x24, 0x34, 0x31, 0x32])
+def test_device_launch_variants(dev, variant):
+    from raft_amd.device import DeviceBatch
+    for n in (3, 5, 9):
+        for G, ld in ((4099, 4352), (65536, 65536), (70001, 70001)):
+            b = synth.gen_adversarial(G, n, seed=variant * 31 + n, ld=ld)
+            exp = o.fused_round(*b.fused_args(), G=G)
+            db = DeviceBatch(b)
+            dev.fused_round(db, variant=variant)
+            _check_dev(db.results(), exp, G)
+
+
+def test_device_in_place_rounds_are_idempotent(dev):
+    """Applying a round in place twice: the second round sees cur' and commit'
+    and must change nothing (max is idempotent; N > commit' is false)."""
+    from raft_amd.device import DeviceBatch
+    b = synth.gen_fused(50000, 5, seed=9)
+    exp = o.fused_round(*b.fused_args())
+    db = DeviceBatch(b, in_place=True)
+    dev.fused_round(db)
+    r1 = db.results()
+    _check_dev(r1, exp, b.G)
+    dev.fused_round(db)
+    r2 = db.results()
+    assert np.array_equal(r2["commit"], r1["commit"]) and np.array_equal(r2["voter_term"], r1["voter_term"])
+    assert not r2["stepdown_mask"].any()
+    b2 = synth.Batch(b); b2["commit"] = exp["commit"]; b2["voter_term"] = exp["voter_term"]
+    exp2 = o.fused_round(*b2.fused_args())
+    _check_dev(r2, exp2, b.G)
+
+
+def test_device_joint_and_split_kernels(dev):
+    from raft_amd.device import DeviceBatch
+    b = synth.gen_mixed(30000, seed=4)
+    exp = o.fused_round(*b.fused_args(), old_mask=b.old_mask, new_mask=b.new_mask)
+    for variant in (0, 1, 2):
+        db = DeviceBatch(b)
+        dev.fused_round(db, variant=variant)
+        _check_dev(db.results(), exp, b.G, member_matrix(b))
+    b = synth.gen_adversarial(20001, 5, seed=8)
+    exp = o.fused_round(*b.fused_args())
+    db = DeviceBatch(b)
+    dev.commit_advance(db)
+    dev.vote_tally(db)
+    res = db.results()
+    assert np.array_equal(res["commit"], exp["commit"])
+    for f in ("grant_mask", "stepdown_mask", "elected", "max_term"):
+        assert np.array_equal(res[f], exp[f]), f
+
+
+def test_upload_step_download(engine):
+    b = synth.gen_fused(100000, 5, seed=21)
+    exp = o.fused_round(*b.fused_args())
+    engine.upload(*b.fused_args())
+    engine.step(1)
+    r = engine.download()
+    assert np.array_equal(r.commit, exp.commit)
+    assert_vote_equal(r, exp, b.G)
+    engine.step(3)                      # further rounds on applied state change nothing
+    r2 = engine.download()
+    assert np.array_equal(r2.commit, r.commit) and np.array_equal(r2.voter_term, r.voter_term)
+
+
+# ---------------------------------------------------------------------------
+# full size: 1M groups x 5 peers
+# ---------------------------------------------------------------------------
+def test_full_size_1m_by_5(engine):
+    G = 1 << 20
+    b = synth.gen_fused(G, 5)
+    got = engine.fused_round(*b.fused_args())
+    exp = o.fused_round(*b.fused_args())
+    assert np.array_equal(got.commit, exp.commit)
+    assert_vote_equal(got, exp, G)
+    # size-independent properties
+    assert (got.commit >= b.commit).all()                       # never moves back
+    N = np.sort(b.match, axis=0)[2]
+    assert ((got.commit == b.commit) | (got.commit == N)).all()  # either stays or jumps to the quorum index
+    assert (got.voter_term >= b.voter_term).all() and (got.voter_term >= b.cand_term[None, :]).all()
+    votes = np.zeros(G, np.int64)
+    for p in range(5):
+        votes += (got.grant_mask >> p) & 1
+    assert np.array_equal(got.elected.astype(bool), (2 * votes > 5) & (got.max_term == b.cand_term))
+    assert 0.2 < got.elected.mean() < 0.9 and 0.1 < (got.commit != b.commit).mean() < 0.6
+    # permutation invariance of the slot order on the commit side
+    perm = np.array([3, 0, 4, 1, 2])
+    c2, _ = engine.commit_advance(b.match[perm], b.commit, b.leader_term, b.log_off, b.log_term)
+    assert np.array_equal(c2, got.commit)
