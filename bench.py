@@ -3,8 +3,9 @@
 
 A step = one fused round (RequestVote tally + commitIndex advance with the
 log-term gather) over this rank's 1M groups x 5 peers, inputs resident in HBM.
-Input sets rotate (default 4 sets, > 512 MB in total) so that the 256 MB
-Infinity Cache cannot serve a step from on-die memory.  With N > 1 ranks the
+Input/output sets rotate (default 12 sets, ~2.1 GB in total: both the reads
+and the 36 MB of writes per step exceed the 256 MB Infinity Cache, which
+otherwise absorbs the writes of up to 5 sets and flatters the number).  With N > 1 ranks the
 groups are sharded (weak scaling: 1M groups per GPU) and every step also
 all-gathers the commit/elected summary over RCCL, overlapped with the next
 step's kernel.
@@ -40,9 +41,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--groups", type=int, default=1 << 20, help="groups per GPU")
     ap.add_argument("--peers", type=int, default=5)
-    ap.add_argument("--sets", type=int, default=4, help="rotating input sets (Infinity Cache defeat)")
+    ap.add_argument("--sets", type=int, default=12,
+                    help="rotating input+output sets; 12 x ~176 MB keeps reads AND writes out of the 256 MB Infinity Cache")
     ap.add_argument("--variant", type=lambda s: int(s, 0), default=0, help="kernel build selector")
     ap.add_argument("--workload", choices=["fused", "mixed"], default="fused")
+    ap.add_argument("--what", choices=["fused", "commit", "vote"], default="fused")
+    ap.add_argument("--ld-pad", type=int, default=256,
+                    help="plane stride = groups + pad (elements): keeps the slot planes off one power-of-two stride")
+    ap.add_argument("--skew", type=int, default=-1, help="one slab per set, arrays skewed by this many bytes (-1: separate allocations)")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
@@ -103,15 +109,17 @@ def main():
     for s in range(S):
         seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
         if args.workload == "fused":
-            b = synth.gen_fused(G, n, seed=seed)
+            b = synth.gen_fused(G, n, seed=seed, ld=G + args.ld_pad)
         else:
             b = synth.gen_mixed(G, seed=seed)
         kw = {}
         if ex is not None:
             kw = dict(commit_out=ex.commit_view(s), elected_bits=ex.bits_view(s))
+        if args.skew >= 0:
+            kw["skew_bytes"] = args.skew
         sets.append(DeviceBatch(b, device, **kw))
     if args.workload == "fused":
-        bytes_per_group = alg_bytes_per_group(n)
+        bytes_per_group = alg_bytes_per_group(n, args.what)
         workload = "%d groups x %d peers per GPU, fused RequestVote tally + commitIndex advance with log-term gather" % (G, n)
     else:
         om = b.old_mask.astype("int64"); nm = b.new_mask.astype("int64")
@@ -124,7 +132,12 @@ def main():
         s = i % S
         if ex is not None:
             ex.wait(s)                       # slot s's previous all-gather must be done
-        eng.fused_round(sets[s], variant=args.variant, want_bits=True, status=True)
+        if args.what == "fused":
+            eng.fused_round(sets[s], variant=args.variant, want_bits=True, status=True)
+        elif args.what == "commit":
+            eng.commit_advance(sets[s], variant=args.variant)
+        else:
+            eng.vote_tally(sets[s], variant=args.variant)
         if ex is not None:
             ex.exchange(s, async_op=True)
 
@@ -180,7 +193,7 @@ def main():
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
                        "resident_mb_per_gpu": round(resident_mb, 1),
-                       "summary_allgather": bool(exchange), "variant": args.variant,
+                       "summary_allgather": bool(exchange), "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "skew": args.skew,
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

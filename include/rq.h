@@ -130,8 +130,10 @@ int rq_fused_round(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
  * group (bit p = slot p).  Commit: N = min(quorum index of old members,
  * quorum index of new members), each over its own member count.  Election:
  * strict majority of grants in BOTH configurations.  Slots outside old|new
- * are not evaluated and their voter_term_out is left unwritten.  Mixed
- * cluster sizes are expressed as old_mask == new_mask == (1<<n_g)-1. */
+ * are not evaluated; their voter_term_out keeps the input value on the host
+ * entry points and in-place device use (out-of-place device launches leave it
+ * unwritten or copy the input).  Mixed cluster sizes are expressed as
+ * old_mask == new_mask == (1<<n_g)-1. */
 int rq_commit_advance_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
                             const uint16_t *old_mask, const uint16_t *new_mask,
                             const int32_t *match, const int32_t *commit,
@@ -172,7 +174,8 @@ int rq_follower_clamp(rq_engine *e, uint64_t count, const int32_t *leader_commit
  * inputs) into the engine's device buffers; rq_step runs `rounds` fused
  * rounds on them with no host transfer (voter terms and commitIndex are
  * updated in place, as the Go host would apply them); rq_download copies the
- * current outputs back.  Any output pointer may be NULL to skip it. */
+ * current outputs back (voter_term_out dense, [n][G]).  Any output pointer may
+ * be NULL to skip it. */
 int rq_upload(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
               const int32_t *match, const int32_t *commit,
               const int32_t *leader_term, const uint32_t *log_off,
@@ -188,7 +191,8 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
 /* ---- asynchronous launches on caller-owned DEVICE buffers --------------- *
  * For hosts that keep group state resident in HBM (and for benchmarking
  * without PCIe in the loop).  Every pointer is a device pointer on the
- * engine's device; `stream` is a hipStream_t (NULL = the engine's stream).
+ * engine's device; `stream` is a hipStream_t used as given (NULL = the device's
+ * default stream, which is also what torch calls its default stream).
  * The launch is enqueued and the call returns without synchronising.
  * elected_bits, if not NULL, receives the elected decisions packed 1 bit per
  * group ([ceil(G/64)] uint64, bit g%64 of word g/64): the summary vector

@@ -476,8 +476,7 @@ static int dev_launch(rq_engine *e, void *stream, int variant, uint32_t n, bool 
             return RQ_E_ARG;
     if (joint && (!a.old_mask || !a.new_mask)) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
-    hipStream_t s = stream ? (hipStream_t)stream : e->stream;
-    hipError_t err = rq_launch_round(a, n, joint, what, variant, s);
+    hipError_t err = rq_launch_round(a, n, joint, what, variant, (hipStream_t)stream);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;
@@ -561,7 +560,7 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G
 int rq_stream_sync(rq_engine *e, void *stream) {
     if (!e) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
-    RQ_HIP(e, hipStreamSynchronize(stream ? (hipStream_t)stream : e->stream));
+    RQ_HIP(e, hipStreamSynchronize((hipStream_t)stream));
     return RQ_OK;
 }
 

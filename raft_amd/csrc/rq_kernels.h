@@ -37,15 +37,21 @@ struct rq_round_args {
 };
 
 // Kernel build selector ("variant" in the C-ABI).  Never changes results.
-//   bits 0-3  groups per thread V: 0 = library default, else 1, 2 or 4
+//   0         library default for the kernel family (see RQ_VAR_DEFAULT_*)
+//   bits 0-3  groups per thread V: 1, 2 or 4 (0 = 1)
 //   bit  4    non-temporal loads of the streamed planes
 //   bit  5    non-temporal stores of the outputs
-//   bit  6    stage the block's contiguous log-arena segment through LDS
-//             instead of gathering log[N] straight from global memory
+//   bits 8-11 threads per block / 64: 1..4 (0 = 256 threads)
+// Measured on MI355X at 1M groups x 5 slots: one group per thread in
+// 128-thread blocks with non-temporal loads and stores is the fastest fused
+// round (many short blocks keep reads, gathers and writes of different blocks
+// overlapped in time; the streamed planes are read once, so keeping them out
+// of L2/MALL leaves the caches to the log-term gather).
 #define RQ_VAR_V_MASK   0x0F
 #define RQ_VAR_NT_LOAD  0x10
 #define RQ_VAR_NT_STORE 0x20
-#define RQ_VAR_LDS_LOG  0x40
+#define RQ_VAR_DEFAULT_FIXED 0x231
+#define RQ_VAR_DEFAULT_JOINT 0x402
 
 #define RQ_WHAT_COMMIT 1
 #define RQ_WHAT_VOTE   2

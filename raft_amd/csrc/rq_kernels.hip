@@ -326,7 +326,7 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
 
 template <int N, int V, int WHAT, int FLAGS>
 __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args a) {
-    const uint64_t g0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     uint32_t el_field = 0;
     if (g0 + V <= a.G)
         el_field = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V);
@@ -514,7 +514,7 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
 
 template <int MMAX, int V, int WHAT, int FLAGS>
 __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args a) {
-    const uint64_t g0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * V;
+    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     uint32_t el_field;
     // Every lane runs a body: the wave-wide ballots inside need all of them.
     if (g0 + V <= a.G)
@@ -557,41 +557,47 @@ __global__ __launch_bounds__(kBlock) void rq_follower_clamp_kernel(
 // dispatch
 // ---------------------------------------------------------------------------
 template <int N, int V, int WHAT, int FLAGS>
-hipError_t launch_fixed(const rq_round_args &a, hipStream_t s) {
+hipError_t launch_fixed(const rq_round_args &a, uint32_t block, hipStream_t s) {
     const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
-    const uint32_t grid = (uint32_t)((threads + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((rq_round_fixed<N, V, WHAT, FLAGS>), dim3(grid), dim3(kBlock), 0, s, a);
+    const uint32_t grid = (uint32_t)((threads + block - 1) / block);
+    hipLaunchKernelGGL((rq_round_fixed<N, V, WHAT, FLAGS>), dim3(grid), dim3(block), 0, s, a);
     return hipGetLastError();
 }
 
 template <int N, int V, int WHAT>
-hipError_t launch_fixed_flags(const rq_round_args &a, int flags, hipStream_t s) {
-    // the cache-policy builds exist for the fused round only
-    if constexpr (WHAT != (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) return launch_fixed<N, V, WHAT, 0>(a, s);
-    else
-    switch (flags & (RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE)) {
-    case 0: return launch_fixed<N, V, WHAT, 0>(a, s);
-    case RQ_VAR_NT_LOAD: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD>(a, s);
-    case RQ_VAR_NT_STORE: return launch_fixed<N, V, WHAT, RQ_VAR_NT_STORE>(a, s);
-    default: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE>(a, s);
+hipError_t launch_fixed_flags(const rq_round_args &a, int flags, uint32_t block, hipStream_t s) {
+    constexpr int kNt = RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE;
+    // the single-policy builds exist for the fused round only (tuning knobs);
+    // the split kernels come in "all non-temporal" and "all default" builds
+    if constexpr (WHAT != (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) {
+        if ((flags & kNt) == kNt) return launch_fixed<N, V, WHAT, kNt>(a, block, s);
+        return launch_fixed<N, V, WHAT, 0>(a, block, s);
+    } else {
+        switch (flags & kNt) {
+        case 0: return launch_fixed<N, V, WHAT, 0>(a, block, s);
+        case RQ_VAR_NT_LOAD: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD>(a, block, s);
+        case RQ_VAR_NT_STORE: return launch_fixed<N, V, WHAT, RQ_VAR_NT_STORE>(a, block, s);
+        default: return launch_fixed<N, V, WHAT, kNt>(a, block, s);
+        }
     }
 }
 
 template <int N, int WHAT>
-hipError_t launch_fixed_v(const rq_round_args &a, int v, int flags, hipStream_t s) {
+hipError_t launch_fixed_v(const rq_round_args &a, int v, int flags, uint32_t block, hipStream_t s) {
     switch (v) {
-    case 1: return launch_fixed_flags<N, 1, WHAT>(a, flags, s);
-    case 2: return launch_fixed_flags<N, 2, WHAT>(a, flags, s);
-    default: return launch_fixed_flags<N, 4, WHAT>(a, flags, s);
+    case 1: return launch_fixed_flags<N, 1, WHAT>(a, flags, block, s);
+    case 2: return launch_fixed_flags<N, 2, WHAT>(a, flags, block, s);
+    default: return launch_fixed_flags<N, 4, WHAT>(a, flags, block, s);
     }
 }
 
 template <int N>
-hipError_t launch_fixed_what(const rq_round_args &a, int what, int v, int flags, hipStream_t s) {
+hipError_t launch_fixed_what(const rq_round_args &a, int what, int v, int flags, uint32_t block,
+                             hipStream_t s) {
     switch (what) {
-    case RQ_WHAT_COMMIT: return launch_fixed_v<N, RQ_WHAT_COMMIT>(a, v, flags, s);
-    case RQ_WHAT_VOTE: return launch_fixed_v<N, RQ_WHAT_VOTE>(a, v, flags, s);
-    default: return launch_fixed_v<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, s);
+    case RQ_WHAT_COMMIT: return launch_fixed_v<N, RQ_WHAT_COMMIT>(a, v, flags, block, s);
+    case RQ_WHAT_VOTE: return launch_fixed_v<N, RQ_WHAT_VOTE>(a, v, flags, block, s);
+    default: return launch_fixed_v<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, block, s);
     }
 }
 
@@ -653,23 +659,27 @@ hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint, int w
     if (a.G == 0) return hipSuccess;
     if (a.G > 0x7FFFFFFFu || a.ld < a.G) return hipErrorInvalidValue;
     if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
-    const int flags = variant & ~RQ_VAR_V_MASK;
+    if (variant == 0) variant = joint || n > 9 ? RQ_VAR_DEFAULT_JOINT : RQ_VAR_DEFAULT_FIXED;
+    const int flags = variant & 0xF0;
     int want = variant & RQ_VAR_V_MASK;
-    if (want != 0 && want != 1 && want != 2 && want != 4) return hipErrorInvalidValue;
+    if (want == 0) want = 1;
+    if (want != 1 && want != 2 && want != 4) return hipErrorInvalidValue;
+    const int bsel = (variant >> 8) & 0xF;
+    if (bsel > 4) return hipErrorInvalidValue;
+    const uint32_t block = bsel ? 64u * (uint32_t)bsel : (uint32_t)kBlock;
 
     if (!joint && n >= 1 && n <= 9) {
-        if (want == 0) want = 4;
         const int v = pick_v(a, want, what);
         switch (n) {
-        case 1: return launch_fixed_what<1>(a, what, v, flags, stream);
-        case 2: return launch_fixed_what<2>(a, what, v, flags, stream);
-        case 3: return launch_fixed_what<3>(a, what, v, flags, stream);
-        case 4: return launch_fixed_what<4>(a, what, v, flags, stream);
-        case 5: return launch_fixed_what<5>(a, what, v, flags, stream);
-        case 6: return launch_fixed_what<6>(a, what, v, flags, stream);
-        case 7: return launch_fixed_what<7>(a, what, v, flags, stream);
-        case 8: return launch_fixed_what<8>(a, what, v, flags, stream);
-        default: return launch_fixed_what<9>(a, what, v, flags, stream);
+        case 1: return launch_fixed_what<1>(a, what, v, flags, block, stream);
+        case 2: return launch_fixed_what<2>(a, what, v, flags, block, stream);
+        case 3: return launch_fixed_what<3>(a, what, v, flags, block, stream);
+        case 4: return launch_fixed_what<4>(a, what, v, flags, block, stream);
+        case 5: return launch_fixed_what<5>(a, what, v, flags, block, stream);
+        case 6: return launch_fixed_what<6>(a, what, v, flags, block, stream);
+        case 7: return launch_fixed_what<7>(a, what, v, flags, block, stream);
+        case 8: return launch_fixed_what<8>(a, what, v, flags, block, stream);
+        default: return launch_fixed_what<9>(a, what, v, flags, block, stream);
         }
     }
     // per-group membership, or a fixed size beyond the register networks
@@ -677,7 +687,7 @@ hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint, int w
     if (!joint) { b.m = n; b.old_mask = nullptr; b.new_mask = nullptr; }
     if (b.m < 1 || b.m > 16) return hipErrorInvalidValue;
     if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
-    if (want == 0 || want > 2) want = 2;
+    if (want > 2) want = 2;
     const int v = pick_v(b, want, what);
     if (b.m <= 8) return launch_joint_what<8>(b, what, v, stream);
     return launch_joint_what<16>(b, what, v, stream);

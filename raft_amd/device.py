@@ -26,33 +26,62 @@ class DeviceBatch:
     IN_KEYS = ("match", "commit", "leader_term", "log_off", "log_term",
                "voter_term", "voted_for", "last_log_term", "cand_term", "cand_id")
 
-    def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None):
+    def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
+                 skew_bytes=None):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
-        sharded.SummaryExchange slot) for the kernel to write its summary into."""
+        sharded.SummaryExchange slot) for the kernel to write its summary into.
+        skew_bytes: if not None, every array is carved from ONE device slab and
+        consecutive arrays are offset by an extra skew_bytes, so that the ~26
+        concurrently streamed arrays do not all sit at the same offset modulo a
+        large power of two (HBM channel/bank aliasing)."""
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
-        self.t = {}
+        G, n, ld = self.G, self.n, self.ld
+        self.joint = "old_mask" in batch
+        host = {}
         for k in self.IN_KEYS:
             a = batch[k]
             if a.dtype == np.uint32:            # torch has no uint32 arithmetic; same bits
                 a = a.view(np.int32)
             if a.size == 0:
                 a = np.zeros(1, a.dtype)
-            self.t[k] = _dev(a, self.device)
-        self.joint = "old_mask" in batch
+            host[k] = np.ascontiguousarray(a)
         if self.joint:
-            self.t["old_mask"] = _dev(batch["old_mask"].view(np.int16), self.device)
-            self.t["new_mask"] = _dev(batch["new_mask"].view(np.int16), self.device)
-        G, n, ld = self.G, self.n, self.ld
-        o = {}
-        o["commit_out"] = self.t["commit"] if in_place else torch.zeros(G, dtype=torch.int32, device=self.device)
-        o["voter_term_out"] = self.t["voter_term"] if in_place else torch.zeros((n, ld), dtype=torch.int32, device=self.device)
-        o["grant_mask"] = torch.zeros(G, dtype=torch.int16, device=self.device)
-        o["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device=self.device)
-        o["elected"] = torch.zeros(G, dtype=torch.uint8, device=self.device)
-        o["max_term"] = torch.zeros(G, dtype=torch.int32, device=self.device)
-        o["status"] = torch.zeros(G, dtype=torch.uint8, device=self.device)
-        o["elected_bits"] = torch.zeros((G + 63) // 64, dtype=torch.int64, device=self.device)
+            host["old_mask"] = np.ascontiguousarray(batch["old_mask"].view(np.int16))
+            host["new_mask"] = np.ascontiguousarray(batch["new_mask"].view(np.int16))
+        outs = [("commit_out", (G,), torch.int32), ("voter_term_out", (n, ld), torch.int32),
+                ("grant_mask", (G,), torch.int16), ("stepdown_mask", (G,), torch.int16),
+                ("elected", (G,), torch.uint8), ("max_term", (G,), torch.int32),
+                ("status", (G,), torch.uint8), ("elected_bits", ((G + 63) // 64,), torch.int64)]
+        self.t, o = {}, {}
+        if skew_bytes is None:
+            for k, a in host.items():
+                self.t[k] = torch.from_numpy(a).to(self.device)
+            for k, shape, dt in outs:
+                o[k] = torch.zeros(shape, dtype=dt, device=self.device)
+        else:
+            np2t = {np.dtype(np.int32): torch.int32, np.dtype(np.int16): torch.int16}
+            plan, off = [], 0
+            for k, a in host.items():
+                plan.append((k, off, a.shape, np2t[a.dtype], a))
+                off += (a.nbytes + 255) // 256 * 256 + skew_bytes
+            for k, shape, dt in outs:
+                nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
+                plan.append((k, off, shape, dt, None))
+                off += (nbytes + 255) // 256 * 256 + skew_bytes
+            self.slab = torch.zeros(off + 256, dtype=torch.uint8, device=self.device)
+            for k, o0, shape, dt, a in plan:
+                cnt = int(np.prod(shape))
+                esz = torch.empty(0, dtype=dt).element_size()
+                v = self.slab[o0:o0 + cnt * esz].view(dt).view(shape)
+                if a is not None:
+                    v.copy_(torch.from_numpy(a))
+                    self.t[k] = v
+                else:
+                    o[k] = v
+        if in_place:
+            o["commit_out"] = self.t["commit"]
+            o["voter_term_out"] = self.t["voter_term"]
         if commit_out is not None:
             assert commit_out.numel() == G and commit_out.dtype == torch.int32
             o["commit_out"] = commit_out
@@ -60,6 +89,7 @@ class DeviceBatch:
             assert elected_bits.numel() == (G + 63) // 64 and elected_bits.dtype == torch.int64
             o["elected_bits"] = elected_bits
         self.o = o
+        self._args = {}
 
     def bytes_resident(self):
         return sum(x.numel() * x.element_size() for x in list(self.t.values()) + list(self.o.values()))
@@ -107,19 +137,24 @@ class DeviceEngine:
 
     def fused_round(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
         """Enqueue one fused round for DeviceBatch b on torch's current stream."""
-        t, o = b.t, b.o
-        p = lambda x: x.data_ptr()
-        tail = [p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
-                p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
-                p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
-                p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
-                p(o["elected_bits"]) if want_bits else None]
+        key = (want_bits, status)
+        tail = b._args.get(key)
+        if tail is None:                      # pointer marshalling is done once per batch
+            t, o = b.t, b.o
+            p = lambda x: x.data_ptr()
+            tail = [p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
+                    p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
+                    p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
+                    p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
+                    p(o["elected_bits"]) if want_bits else None]
+            if b.joint:
+                tail = [p(t["old_mask"]), p(t["new_mask"])] + tail
+            b._args[key] = tail
         if b.joint:
-            rc = self._l.rq_fused_round_joint_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
-                                                  p(t["old_mask"]), p(t["new_mask"]), *tail)
-            self._check(rc, "rq_fused_round_joint_dev")
+            rc = self._l.rq_fused_round_joint_dev(self._h, self._stream(), variant, b.G, b.n, b.ld, *tail)
         else:
             rc = self._l.rq_fused_round_dev(self._h, self._stream(), variant, b.G, b.n, b.ld, *tail)
+        if rc != 0:
             self._check(rc, "rq_fused_round_dev")
 
     def commit_advance(self, b, variant=VAR_DEFAULT):
