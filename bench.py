@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--skew", type=int, default=-1, help="one slab per set, arrays skewed by this many bytes (-1: separate allocations)")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
+    ap.add_argument("--no-status", action="store_true", help="skip the per-group status byte output")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
@@ -133,7 +135,7 @@ def main():
         if ex is not None:
             ex.wait(s)                       # slot s's previous all-gather must be done
         if args.what == "fused":
-            eng.fused_round(sets[s], variant=args.variant, want_bits=True, status=True)
+            eng.fused_round(sets[s], variant=args.variant, want_bits=not args.no_bits, status=not args.no_status)
         elif args.what == "commit":
             eng.commit_advance(sets[s], variant=args.variant)
         else:

@@ -38,6 +38,7 @@ for f in find("kt/**/*kernel_trace.csv"):
     print("  launches=%d  median_ns=%d  mean_ns=%.0f  p10=%d p90=%d  vgpr/sgpr/lds/wg/grid=%s" % (
         len(dur[dom]), d[len(d) // 2], sum(d) / len(d), d[len(d) // 10], d[9 * len(d) // 10], meta[dom]))
 print("\n## PMC counters, average per launch of the dominant kernel")
+avg = {}
 for f in find("pmc*/**/*counter_collection.csv"):
     rows = list(csv.DictReader(open(f)))
     acc = defaultdict(list)
@@ -46,4 +47,28 @@ for f in find("pmc*/**/*counter_collection.csv"):
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for c, v in acc.items():
         v = v[len(v) // 6:]
-        print("  %-28s avg=%.1f  (n=%d)" % (c, sum(v) / len(v), len(v)))
+        avg[c] = sum(v) / len(v)
+        print("  %-28s avg=%.1f  (n=%d)" % (c, avg[c], len(v)))
+
+# HBM bytes per launch.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+# counts each 128-byte read request as 64 bytes, so it is doubled; the raw request
+# counters (32/64/128-byte reads, 64-byte writes) give the same total independently.
+if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
+    rd = 2.0 * avg["FETCH_SIZE"] * 1024.0
+    wr = avg["WRITE_SIZE"] * 1024.0
+    print("\n## HBM traffic per launch")
+    print("  reads  (2 x FETCH_SIZE KiB): %.1f MB" % (rd / 1e6))
+    print("  writes (WRITE_SIZE KiB)    : %.1f MB" % (wr / 1e6))
+    if "TCC_EA0_RDREQ_128B_sum" in avg:
+        rd_raw = (128 * avg["TCC_EA0_RDREQ_128B_sum"] + 64 * avg.get("TCC_EA0_RDREQ_64B_sum", 0)
+                  + 32 * avg.get("TCC_EA0_RDREQ_32B_sum", 0))
+        print("  reads  from request counters: %.1f MB" % (rd_raw / 1e6))
+    if "TCC_EA0_WRREQ_sum" in avg:
+        w64 = avg.get("TCC_EA0_WRREQ_64B_sum", 0)
+        wr_raw = 64 * w64 + 32 * (avg["TCC_EA0_WRREQ_sum"] - w64)
+        print("  writes from request counters: %.1f MB" % (wr_raw / 1e6))
+    print("  total: %.1f MB" % ((rd + wr) / 1e6))
+    import json
+    json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+               "kernel": dom, "source": os.path.basename(root)},
+              open(os.path.join(root, "traffic.json"), "w"))
