@@ -50,6 +50,7 @@ def parse():
                     help="plane stride = groups + pad (elements): keeps the slot planes off one power-of-two stride")
     ap.add_argument("--skew", type=int, default=-1, help="one slab per set, arrays skewed by this many bytes (-1: separate allocations)")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
     ap.add_argument("--no-status", action="store_true", help="skip the per-group status byte output")
@@ -96,14 +97,18 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()    # one rank per GPU on a real node
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     G, n, S = args.groups, args.peers, max(1, args.sets)
-    eng = DeviceEngine(local_rank)
+    eng = DeviceEngine(dev_index)
     exchange = world > 1 and not args.no_exchange
     ex = SummaryExchange(G, device, depth=S) if exchange else None
 

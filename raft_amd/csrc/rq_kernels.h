@@ -10,6 +10,7 @@ struct rq_round_args {
     uint32_t G;
     uint32_t ld;
     uint32_t m;  // joint kernels: number of slot planes
+    uint32_t gather_policy;  // set by rq_launch_round from the variant word
     // commit side (Node.matchIndex / commitIndex / currentTerm / log, raft.go:35-68)
     const int32_t  *match;
     const int32_t  *commit;
@@ -41,16 +42,17 @@ struct rq_round_args {
 //   bits 0-3  groups per thread V: 1, 2 or 4 (0 = 1)
 //   bit  4    non-temporal loads of the streamed planes
 //   bit  5    non-temporal stores of the outputs
+//   bits 6-7  cache policy of the log-term gather: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
 //   bits 8-11 threads per block / 64: 1..4 (0 = 256 threads)
 // Measured on MI355X at 1M groups x 5 slots: one group per thread in
 // 128-thread blocks with non-temporal loads and stores is the fastest fused
 // round (many short blocks keep reads, gathers and writes of different blocks
-// overlapped in time; the streamed planes are read once, so keeping them out
-// of L2/MALL leaves the caches to the log-term gather).
+// overlapped in time; every byte is touched once per round, so nothing is
+// worth keeping in L2 or the Infinity Cache, the gathered log lines included).
 #define RQ_VAR_V_MASK   0x0F
 #define RQ_VAR_NT_LOAD  0x10
 #define RQ_VAR_NT_STORE 0x20
-#define RQ_VAR_DEFAULT_FIXED 0x231
+#define RQ_VAR_DEFAULT_FIXED 0x271
 #define RQ_VAR_DEFAULT_JOINT 0x402
 
 #define RQ_WHAT_COMMIT 1

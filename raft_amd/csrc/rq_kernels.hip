@@ -217,6 +217,18 @@ __device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32
 
 constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02;
 
+// The one dependent, data-indexed load of a round: log[N].TermNum.  `policy`
+// is wave-uniform (kernel argument): 0 plain, 1 non-temporal, 2 agent-scope
+// (sc1), 3 system-scope (sc0 sc1).
+__device__ __forceinline__ int32_t gather_term(const int32_t *p, uint32_t policy) {
+    switch (policy) {
+    case 1: return __builtin_nontemporal_load(p);
+    case 2: return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    case 3: return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    default: return *p;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // fixed cluster size n = N for every group
 // ---------------------------------------------------------------------------
@@ -244,7 +256,7 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
         const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
         int32_t o[V];
         ld_i32<V, NTL, FULL>(offp, valid, o);
-        const int32_t oend = offp[valid];  // log_off has G+1 entries
+        const int32_t oend = NTL ? __builtin_nontemporal_load(offp + valid) : offp[valid];  // log_off has G+1 entries
 #pragma unroll
         for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
         off[V] = oend;
@@ -274,7 +286,7 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
             adv[k] = (k < valid) && nq[k] > cm[k];
             inb[k] = (uint32_t)nq[k] < len;
             gt[k] = 0;
-            if (adv[k] && inb[k]) gt[k] = a.log_term[(size_t)(uint32_t)off[k] + (uint32_t)nq[k]];
+            if (adv[k] && inb[k]) gt[k] = gather_term(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]), a.gather_policy);
         }
     }
 
@@ -435,7 +447,7 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
             adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
             inb[k] = (uint32_t)nq[k] < len;
             gt[k] = 0;
-            if (adv[k] && inb[k]) gt[k] = a.log_term[(size_t)(uint32_t)off[k] + (uint32_t)nq[k]];
+            if (adv[k] && inb[k]) gt[k] = gather_term(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]), a.gather_policy);
         }
     }
 
@@ -654,13 +666,15 @@ int pick_v(const rq_round_args &a, int want, int what) {
 
 }  // namespace
 
-hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint, int what,
+hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, int what,
                            int variant, hipStream_t stream) {
-    if (a.G == 0) return hipSuccess;
-    if (a.G > 0x7FFFFFFFu || a.ld < a.G) return hipErrorInvalidValue;
+    if (args.G == 0) return hipSuccess;
+    if (args.G > 0x7FFFFFFFu || args.ld < args.G) return hipErrorInvalidValue;
     if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
     if (variant == 0) variant = joint || n > 9 ? RQ_VAR_DEFAULT_JOINT : RQ_VAR_DEFAULT_FIXED;
-    const int flags = variant & 0xF0;
+    rq_round_args a = args;
+    a.gather_policy = (uint32_t)(variant >> 6) & 3u;
+    const int flags = variant & 0x30;
     int want = variant & RQ_VAR_V_MASK;
     if (want == 0) want = 1;
     if (want != 1 && want != 2 && want != 4) return hipErrorInvalidValue;
