@@ -84,6 +84,9 @@ def cpu_baseline(args, synth):
 
 def main():
     args = parse()
+    if os.environ.get("RQ_BENCH_TRACE_AFTER"):       # debugging aid: dump Python stacks if stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RQ_BENCH_TRACE_AFTER"]), exit=True)
     import torch
     import torch.distributed as dist
     from raft_amd import synth

@@ -1,0 +1,55 @@
+package raft
+
+/*
+#cgo CFLAGS: -I${SRCDIR}/../../include
+#cgo LDFLAGS: -L${SRCDIR}/../../raft_amd -lrq -Wl,-rpath,${SRCDIR}/../../raft_amd
+#include "rq.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"runtime"
+	"unsafe"
+)
+
+// rqEngine wraps one rq_engine (one GPU, one stream).
+type rqEngine struct{ h *C.rq_engine }
+
+func newRqEngine(device int, maxGroups, maxSlots uint32, maxLogTerms uint64) (*rqEngine, error) {
+	var h *C.rq_engine
+	rc := C.rq_engine_create(C.int(device), C.uint32_t(maxGroups), C.uint32_t(maxSlots),
+		C.uint64_t(maxLogTerms), &h)
+	if rc != C.RQ_OK {
+		return nil, errors.New("rq_engine_create: " + C.GoString(C.rq_strerror(rc)))
+	}
+	e := &rqEngine{h: h}
+	runtime.SetFinalizer(e, func(e *rqEngine) { e.close() })
+	return e, nil
+}
+
+func (e *rqEngine) close() {
+	if e.h != nil {
+		C.rq_engine_destroy(e.h)
+		e.h = nil
+	}
+}
+
+func i32(p []int32) *C.int32_t   { return (*C.int32_t)(unsafe.Pointer(&p[0])) }
+func u32(p []uint32) *C.uint32_t { return (*C.uint32_t)(unsafe.Pointer(&p[0])) }
+func u16(p []uint16) *C.uint16_t { return (*C.uint16_t)(unsafe.Pointer(&p[0])) }
+func u8(p []uint8) *C.uint8_t    { return (*C.uint8_t)(unsafe.Pointer(&p[0])) }
+
+// fusedRound passes only flat scalar slices (no Go pointers inside them), which
+// is what the cgo pointer rules require; librq copies before it returns.
+func (e *rqEngine) fusedRound(b *roundBuffers) error {
+	rc := C.rq_fused_round(e.h, C.uint32_t(b.groups), C.uint32_t(b.slots), C.uint32_t(b.ld),
+		i32(b.match), i32(b.commit), i32(b.leaderTerm), u32(b.logOff), i32(b.logTerm),
+		i32(b.voterTerm), i32(b.votedFor), i32(b.lastLogTerm), i32(b.candTerm), i32(b.candID),
+		i32(b.commitOut), i32(b.voterTermOut), u16(b.grantMask), u16(b.stepdownMask),
+		u8(b.elected), i32(b.maxTerm), u8(b.status))
+	if rc != C.RQ_OK {
+		return errors.New("rq_fused_round: " + C.GoString(C.rq_strerror(rc)))
+	}
+	return nil
+}
