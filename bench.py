@@ -115,16 +115,19 @@ def main():
     exchange = world > 1 and not args.no_exchange
     ex = SummaryExchange(G, device, depth=S) if exchange else None
 
-    sets = []
+    sets, first_mixed = [], None
     for s in range(S):
         seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
         if args.workload == "fused":
             b = synth.gen_fused(G, n, seed=seed, ld=G + args.ld_pad)
-        else:
-            b = synth.gen_mixed(G, seed=seed)
+        else:                                # the 0.9 GB log arena is generated once and shared
+            b = synth.gen_mixed(G, seed=seed, logs_from=first_mixed)
+            first_mixed = first_mixed or b
         kw = {}
+        if args.workload == "mixed" and sets:
+            kw["share_log_with"] = sets[0]
         if ex is not None:
-            kw = dict(commit_out=ex.commit_view(s), elected_bits=ex.bits_view(s))
+            kw.update(commit_out=ex.commit_view(s), elected_bits=ex.bits_view(s))
         if args.skew >= 0:
             kw["skew_bytes"] = args.skew
         sets.append(DeviceBatch(b, device, **kw))

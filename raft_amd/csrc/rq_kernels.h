@@ -53,7 +53,7 @@ struct rq_round_args {
 #define RQ_VAR_NT_LOAD  0x10
 #define RQ_VAR_NT_STORE 0x20
 #define RQ_VAR_DEFAULT_FIXED 0x271
-#define RQ_VAR_DEFAULT_JOINT 0x402
+#define RQ_VAR_DEFAULT_JOINT 0x131
 
 #define RQ_WHAT_COMMIT 1
 #define RQ_WHAT_VOTE   2

@@ -352,6 +352,45 @@ __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args a) {
 }
 
 // ---------------------------------------------------------------------------
+// Quorum index over a member subset: non-members are replaced by INT_MIN, the
+// vector is sorted in DESCENDING order by a Batcher odd-even merge network
+// (19 compare-exchanges for 8 inputs, 63 for 16) and element |cfg|/2 -- the
+// (|cfg|/2+1)-th largest member value -- is selected.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void cexd(int32_t &a, int32_t &b) {
+    int32_t hi = max(a, b), lo = min(a, b);
+    a = hi; b = lo;
+}
+#define D(i, j) cexd(s[i], s[j]);
+__device__ __forceinline__ void sort_desc8(int32_t (&s)[8]) {
+    D(0,1) D(2,3) D(4,5) D(6,7) D(0,2) D(1,3) D(4,6) D(5,7) D(1,2) D(5,6) D(0,4) D(1,5) D(2,6)
+    D(3,7) D(2,4) D(3,5) D(1,2) D(3,4) D(5,6)
+}
+__device__ __forceinline__ void sort_desc16(int32_t (&s)[16]) {
+    D(0,1) D(2,3) D(4,5) D(6,7) D(8,9) D(10,11) D(12,13) D(14,15) D(0,2) D(1,3) D(4,6) D(5,7)
+    D(8,10) D(9,11) D(12,14) D(13,15) D(1,2) D(5,6) D(9,10) D(13,14) D(0,4) D(1,5) D(2,6)
+    D(3,7) D(8,12) D(9,13) D(10,14) D(11,15) D(2,4) D(3,5) D(10,12) D(11,13) D(1,2) D(3,4)
+    D(5,6) D(9,10) D(11,12) D(13,14) D(0,8) D(1,9) D(2,10) D(3,11) D(4,12) D(5,13) D(6,14)
+    D(7,15) D(4,8) D(5,9) D(6,10) D(7,11) D(2,4) D(3,5) D(6,8) D(7,9) D(10,12) D(11,13) D(1,2)
+    D(3,4) D(5,6) D(7,8) D(9,10) D(11,12) D(13,14)
+}
+#undef D
+
+// W = 8 or 16 slots considered; mask has no bit at or above W.
+template <int W, int MMAX, int V>
+__device__ __forceinline__ int32_t masked_quorum(const int32_t (&mt)[MMAX][V], int k, uint32_t mask) {
+    int32_t s[W];
+#pragma unroll
+    for (int p = 0; p < W; p++) s[p] = ((mask >> p) & 1u) ? mt[p][k] : INT_MIN;
+    if constexpr (W == 8) sort_desc8(s); else sort_desc16(s);
+    const int idx = __popc(mask) >> 1;
+    int32_t r = s[0];
+#pragma unroll
+    for (int i = 1; i <= W / 2; i++) r = (idx == i) ? s[i] : r;
+    return r;
+}
+
+// ---------------------------------------------------------------------------
 // per-group membership: m slot planes, old/new member masks (joint consensus,
 // mixed cluster sizes).  Null masks mean "all m slots, one configuration".
 // ---------------------------------------------------------------------------
@@ -398,6 +437,71 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
 #pragma unroll
     for (int k = 0; k < V; k++) st[k] = 0;
 
+    // ---- vote: slots are processed in chunks of kChunk; a chunk's 3*kChunk plane
+    // loads are all issued before any of them is consumed, and chunk 0 is issued
+    // before the commit side's sort so that it is in flight behind it.
+    constexpr int kChunk = 8;
+    uint32_t el_field = 0;
+    int32_t ct[V], ci[V], mx[V];
+    uint32_t gm[V], sm[V];
+    int32_t cvt[kChunk][V], cvf[kChunk][V], cll[kChunk][V];
+    auto issue_chunk = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < kChunk; q++) {
+            const int p = c0 + q;
+#pragma unroll
+            for (int k = 0; k < V; k++) { cvt[q][k] = 0; cvf[q][k] = 0; cll[q][k] = 0; }
+            if (p < MMAX && ((wm >> p) & 1u)) {
+                if ((anymem >> p) & 1u) {
+                    ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, cvt[q]);
+                    ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, cvf[q]);
+                    ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, cll[q]);
+                }
+            }
+        }
+    };
+    auto compute_chunk = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < kChunk; q++) {
+            const int p = c0 + q;
+            if (!(p < MMAX && ((wm >> p) & 1u))) continue;
+            if (!((anymem >> p) & 1u)) continue;
+            int32_t nt[V];
+            bool all_members = true;
+#pragma unroll
+            for (int k = 0; k < V; k++) {
+                const bool member = (mem[k] >> p) & 1u;
+                uint32_t sd, gr, pn;
+                vote_slot(cvt[q][k], cvf[q][k], cll[q][k], ct[k], ci[k], nt[k], sd, gr, pn);
+                if (member) {
+                    gm[k] |= gr << p;
+                    sm[k] |= sd << p;
+                    mx[k] = max(mx[k], nt[k]);
+                    st[k] |= pn ? kStEmptyLog : 0;
+                } else {
+                    nt[k] = cvt[q][k];
+                    if (k < valid) all_members = false;
+                }
+            }
+            if (all_members) {
+                st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
+            } else {
+#pragma unroll
+                for (int k = 0; k < V; k++)
+                    if (k < valid && ((mem[k] >> p) & 1u)) a.voter_term_out[p * ld + g0 + k] = nt[k];
+            }
+        }
+    };
+    if constexpr (DO_VOTE) {
+#pragma unroll
+        for (int k = 0; k < V; k++) { ct[k] = 0; ci[k] = 0; gm[k] = 0; sm[k] = 0; mx[k] = INT_MIN; }
+        if (in_range) {
+            ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
+            ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
+        }
+        issue_chunk(0);
+    }
+
     int32_t nq[V], gt[V], cm[V], lt[V];
     bool adv[V], inb[V];
     if constexpr (DO_COMMIT) {
@@ -425,24 +529,21 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
             for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
             off[V] = oend;
         }
+        // one configuration for the whole wave (the common case) needs one sort
+        bool two_cfgs = false;
+#pragma unroll
+        for (int k = 0; k < V; k++) two_cfgs = two_cfgs || (om[k] != nm[k]);
+        const bool wave_two_cfgs = __ballot(two_cfgs) != 0ull;
+        const bool wave_small = MMAX == 8 || wm < 256u;
 #pragma unroll
         for (int k = 0; k < V; k++) {
-            // N_cfg = max{ match_i : i in cfg, #{j in cfg : match_j >= match_i} >= |cfg|/2+1 }
-            const int majo = (__popc(om[k]) >> 1) + 1, majn = (__popc(nm[k]) >> 1) + 1;
-            int32_t no = INT_MIN, nn = INT_MIN;
-#pragma unroll
-            for (int i = 0; i < MMAX; i++) {
-                if (!((wm >> i) & 1u)) continue;
-                uint32_t ge = 0;
-#pragma unroll
-                for (int j = 0; j < MMAX; j++) {
-                    if (!((wm >> j) & 1u)) continue;
-                    ge |= (mt[j][k] >= mt[i][k]) ? (1u << j) : 0u;
-                }
-                const bool oko = ((om[k] >> i) & 1u) && __popc(ge & om[k]) >= majo;
-                const bool okn = ((nm[k] >> i) & 1u) && __popc(ge & nm[k]) >= majn;
-                no = oko ? max(no, mt[i][k]) : no;
-                nn = okn ? max(nn, mt[i][k]) : nn;
+            int32_t no, nn;
+            if (wave_small) {
+                no = masked_quorum<8, MMAX, V>(mt, k, om[k]);
+                nn = wave_two_cfgs ? masked_quorum<8, MMAX, V>(mt, k, nm[k]) : no;
+            } else if constexpr (MMAX == 16) {
+                no = masked_quorum<16, MMAX, V>(mt, k, om[k]);
+                nn = wave_two_cfgs ? masked_quorum<16, MMAX, V>(mt, k, nm[k]) : no;
             }
             nq[k] = min(no, nn);
             const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
@@ -453,51 +554,15 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
         }
     }
 
-    uint32_t el_field = 0;
     if constexpr (DO_VOTE) {
-        int32_t ct[V], ci[V];
-#pragma unroll
-        for (int k = 0; k < V; k++) { ct[k] = 0; ci[k] = 0; }
-        if (in_range) {
-            ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
-            ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
-        }
-        uint32_t gm[V], sm[V], el[V];
-        int32_t mx[V];
-#pragma unroll
-        for (int k = 0; k < V; k++) { gm[k] = 0; sm[k] = 0; mx[k] = INT_MIN; }
-#pragma unroll
-        for (int p = 0; p < MMAX; p++) {
-            if (!((wm >> p) & 1u)) continue;
-            if (!((anymem >> p) & 1u)) continue;
-            int32_t vt[V], vf[V], ll[V], nt[V];
-            ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, vt);
-            ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, vf);
-            ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, ll);
-            bool all_members = true;
-#pragma unroll
-            for (int k = 0; k < V; k++) {
-                const bool member = (mem[k] >> p) & 1u;
-                uint32_t sd, gr, pn;
-                vote_slot(vt[k], vf[k], ll[k], ct[k], ci[k], nt[k], sd, gr, pn);
-                if (member) {
-                    gm[k] |= gr << p;
-                    sm[k] |= sd << p;
-                    mx[k] = max(mx[k], nt[k]);
-                    st[k] |= pn ? kStEmptyLog : 0;
-                } else {
-                    nt[k] = vt[k];
-                    if (k < valid) all_members = false;
-                }
-            }
-            if (all_members) {
-                st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
-            } else {
-#pragma unroll
-                for (int k = 0; k < V; k++)
-                    if (k < valid && ((mem[k] >> p) & 1u)) a.voter_term_out[p * ld + g0 + k] = nt[k];
+        compute_chunk(0);
+        if constexpr (MMAX > kChunk) {
+            if ((wm >> kChunk) != 0u) {          // wave-uniform: some lane has a slot >= kChunk
+                issue_chunk(kChunk);
+                compute_chunk(kChunk);
             }
         }
+        uint32_t el[V];
 #pragma unroll
         for (int k = 0; k < V; k++) {
             const bool maj_old = 2 * __popc(gm[k] & om[k]) > __popc(om[k]);
@@ -615,28 +680,36 @@ hipError_t launch_fixed_what(const rq_round_args &a, int what, int v, int flags,
     }
 }
 
-template <int MMAX, int V, int WHAT>
-hipError_t launch_joint(const rq_round_args &a, hipStream_t s) {
+template <int MMAX, int V, int WHAT, int FLAGS>
+hipError_t launch_joint(const rq_round_args &a, uint32_t block, hipStream_t s) {
     const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
-    const uint32_t grid = (uint32_t)((threads + kBlock - 1) / kBlock);
-    hipLaunchKernelGGL((rq_round_joint<MMAX, V, WHAT, 0>), dim3(grid), dim3(kBlock), 0, s, a);
+    const uint32_t grid = (uint32_t)((threads + block - 1) / block);
+    hipLaunchKernelGGL((rq_round_joint<MMAX, V, WHAT, FLAGS>), dim3(grid), dim3(block), 0, s, a);
     return hipGetLastError();
 }
 
+template <int MMAX, int V, int WHAT>
+hipError_t launch_joint_flags(const rq_round_args &a, int flags, uint32_t block, hipStream_t s) {
+    constexpr int kNt = RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE;
+    if ((flags & kNt) == kNt) return launch_joint<MMAX, V, WHAT, kNt>(a, block, s);
+    return launch_joint<MMAX, V, WHAT, 0>(a, block, s);
+}
+
 template <int MMAX, int WHAT>
-hipError_t launch_joint_v(const rq_round_args &a, int v, hipStream_t s) {
+hipError_t launch_joint_v(const rq_round_args &a, int v, int flags, uint32_t block, hipStream_t s) {
     switch (v) {
-    case 1: return launch_joint<MMAX, 1, WHAT>(a, s);
-    default: return launch_joint<MMAX, 2, WHAT>(a, s);
+    case 1: return launch_joint_flags<MMAX, 1, WHAT>(a, flags, block, s);
+    default: return launch_joint_flags<MMAX, 2, WHAT>(a, flags, block, s);
     }
 }
 
 template <int MMAX>
-hipError_t launch_joint_what(const rq_round_args &a, int what, int v, hipStream_t s) {
+hipError_t launch_joint_what(const rq_round_args &a, int what, int v, int flags, uint32_t block,
+                             hipStream_t s) {
     switch (what) {
-    case RQ_WHAT_COMMIT: return launch_joint_v<MMAX, RQ_WHAT_COMMIT>(a, v, s);
-    case RQ_WHAT_VOTE: return launch_joint_v<MMAX, RQ_WHAT_VOTE>(a, v, s);
-    default: return launch_joint_v<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, s);
+    case RQ_WHAT_COMMIT: return launch_joint_v<MMAX, RQ_WHAT_COMMIT>(a, v, flags, block, s);
+    case RQ_WHAT_VOTE: return launch_joint_v<MMAX, RQ_WHAT_VOTE>(a, v, flags, block, s);
+    default: return launch_joint_v<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, block, s);
     }
 }
 
@@ -705,8 +778,8 @@ hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, in
     if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
     if (want > 2) want = 2;
     const int v = pick_v(b, want, what);
-    if (b.m <= 8) return launch_joint_what<8>(b, what, v, stream);
-    return launch_joint_what<16>(b, what, v, stream);
+    if (b.m <= 8) return launch_joint_what<8>(b, what, v, flags, block, stream);
+    return launch_joint_what<16>(b, what, v, flags, block, stream);
 }
 
 hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,

@@ -27,19 +27,23 @@ class DeviceBatch:
                "voter_term", "voted_for", "last_log_term", "cand_term", "cand_id")
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
-                 skew_bytes=None):
+                 skew_bytes=None, share_log_with=None):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         skew_bytes: if not None, every array is carved from ONE device slab and
         consecutive arrays are offset by an extra skew_bytes, so that the ~26
         concurrently streamed arrays do not all sit at the same offset modulo a
-        large power of two (HBM channel/bank aliasing)."""
+        large power of two (HBM channel/bank aliasing).
+        share_log_with: another DeviceBatch whose log_off/log_term device arrays
+        are reused (the batch must have been generated with the same logs)."""
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
         G, n, ld = self.G, self.n, self.ld
         self.joint = "old_mask" in batch
         host = {}
         for k in self.IN_KEYS:
+            if share_log_with is not None and k in ("log_off", "log_term"):
+                continue
             a = batch[k]
             if a.dtype == np.uint32:            # torch has no uint32 arithmetic; same bits
                 a = a.view(np.int32)
@@ -79,6 +83,9 @@ class DeviceBatch:
                     self.t[k] = v
                 else:
                     o[k] = v
+        if share_log_with is not None:
+            self.t["log_off"] = share_log_with.t["log_off"]
+            self.t["log_term"] = share_log_with.t["log_term"]
         if in_place:
             o["commit_out"] = self.t["commit"]
             o["voter_term_out"] = self.t["voter_term"]

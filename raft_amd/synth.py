@@ -174,12 +174,13 @@ def masked_quorum_index(match, mask):
     return s[np.maximum(cnt - 1, 0) // 2, np.arange(G)]
 
 
-def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi=9):
+def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi=9, logs_from=None):
     """Mixed 3-9 slot clusters, a fraction in joint consensus (old and new
     configurations overlapping in at least one slot, all within 16 slots),
     Zipf(1.2) log lengths clipped to [1, 4096].  bucketed=True orders groups by
     highest member slot so that waves are homogeneous (a host-side layout
-    choice; results do not depend on it)."""
+    choice; results do not depend on it).  logs_from: a previous gen_mixed batch
+    whose log arena (hundreds of MB at 1M groups) is reused unchanged."""
     m = 16
     g = np.arange(G, dtype=np.int64)
     n_old = n_lo + _below(seed, F_NSLOT, g, n_hi - n_lo + 1)
@@ -194,9 +195,13 @@ def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi
         order = np.argsort(top, kind="stable")
         old_mask, new_mask = old_mask[order], new_mask[order]
     old_mask = old_mask.astype(np.uint16); new_mask = new_mask.astype(np.uint16)
-    lens = _zipf_lens(seed, G)
-    off = _csr(lens)
-    log_term, T = _monotone_log(seed, G, lens, off, 8)
+    if logs_from is None:
+        lens = _zipf_lens(seed, G)
+        off = _csr(lens)
+        log_term, T = _monotone_log(seed, G, lens, off, 8)
+    else:                      # reuse another batch's (large) log arena, redraw everything else
+        off, log_term, T = logs_from["log_off"], logs_from["log_term"], logs_from["log_T"]
+        lens = np.diff(off.astype(np.int64))
 
     def members(match):
         return np.minimum(masked_quorum_index(match, old_mask), masked_quorum_index(match, new_mask))
@@ -205,7 +210,8 @@ def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi
     vt, vf, ll, ct, ci = _vote_side(seed, G, m, G, 2 + T)
     return Batch(G=G, n=m, ld=G, match=match, commit=commit, leader_term=leader_term,
                  log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
-                 last_log_term=ll, cand_term=ct, cand_id=ci, old_mask=old_mask, new_mask=new_mask)
+                 last_log_term=ll, cand_term=ct, cand_id=ci, old_mask=old_mask, new_mask=new_mask,
+                 log_T=T)
 
 
 def gen_adversarial(G, n, seed=DEFAULT_SEED, ld=None):
