@@ -168,6 +168,34 @@ int rq_follower_clamp(rq_engine *e, uint64_t count, const int32_t *leader_commit
                       const int32_t *commit, const int32_t *last_new_index,
                       int32_t *commit_out);
 
+/* AppendEntries receiver-side consistency batch for every (group, follower)
+ * slot s = p*ld + g, and the leader's bookkeeping for the replies.
+ * Receiver (AppendEntriesRPC raft.go:142-153, testToAbdicateLeadership :212-223):
+ *     cur' = max(cur, term); stepdown bit p = term > cur
+ *     success bit p = term >= cur && log[prevLogIndex].TermNum == prevLogTerm
+ * with log[] indexed directly by slot (:151); prevLogIndex outside the
+ * follower's log is an index panic in the reference: RQ_ST_LOG_OOB, no success.
+ * Steps 3-5 of the RPC (:155-176: log mutation, string payloads, commit clamp)
+ * are not part of this call; the clamp is rq_follower_clamp.
+ * Leader (the reference declares nextIndex :60-63 / matchIndex :65-68 and
+ * never updates them; rule: Raft Fig. 2): success -> match = prevLogIndex +
+ * n_new, next = match + 1; rejected at the log check -> next = max(next-1, 1);
+ * rejected for a stale term -> unchanged.
+ * active_mask ([G], bit p; NULL = all n slots) selects the slots that receive
+ * an RPC this round; other slots are left untouched.  Follower logs are one
+ * CSR arena indexed by slot id: flog_term[flog_off[s] .. flog_off[s+1]),
+ * flog_off has n*ld + 1 entries.  n_new, match_index_io, next_index_io and
+ * status_out may be NULL. */
+int rq_append_check(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                    const uint16_t *active_mask,
+                    const int32_t *follower_term, const int32_t *leader_term,
+                    const int32_t *prev_log_index, const int32_t *prev_log_term,
+                    const int32_t *n_new,
+                    const uint32_t *flog_off, const int32_t *flog_term,
+                    int32_t *follower_term_out, uint16_t *success_mask,
+                    uint16_t *stepdown_mask, int32_t *match_index_io,
+                    int32_t *next_index_io, uint8_t *status_out);
+
 /* ---- device-resident round: state stays in HBM between rounds ----------- */
 
 /* rq_upload copies one round's inputs (same arguments as rq_fused_round's
@@ -239,6 +267,15 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant,
                              uint16_t *grant_mask, uint16_t *stepdown_mask,
                              uint8_t *elected, int32_t *max_term,
                              uint8_t *status_out, uint64_t *elected_bits);
+int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
+                        const uint16_t *active_mask,
+                        const int32_t *follower_term, const int32_t *leader_term,
+                        const int32_t *prev_log_index, const int32_t *prev_log_term,
+                        const int32_t *n_new,
+                        const uint32_t *flog_off, const int32_t *flog_term,
+                        int32_t *follower_term_out, uint16_t *success_mask,
+                        uint16_t *stepdown_mask, int32_t *match_index_io,
+                        int32_t *next_index_io, uint8_t *status_out);
 int rq_stream_sync(rq_engine *e, void *stream);
 
 #ifdef __cplusplus

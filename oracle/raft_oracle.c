@@ -223,6 +223,24 @@ int rf_leader_advance_commit(rf_node *l) {
     return RF_OK;
 }
 
+/* Leader bookkeeping for one AppendEntries reply (Raft paper Fig. 2; the
+ * reference only declares nextIndex/matchIndex, raft.go:60-68).  On success
+ * the follower holds everything up to prevLogIndex + n_new.  On a rejection
+ * that got as far as the log check (term was current) the leader backs
+ * nextIndex off by one, never below 1 (indices start at 1, raft.go:43, :108).
+ * A rejection for a stale term changes nothing: the leader is about to step
+ * down on the reply's term. */
+void rf_leader_on_append_reply(rf_node *l, int64_t slot, int success,
+                               int reached_log_check, int64_t prev_log_index,
+                               int64_t n_new) {
+    if (success) {
+        l->match_index[slot] = prev_log_index + n_new;
+        l->next_index[slot] = l->match_index[slot] + 1;
+    } else if (reached_log_check) {
+        if (l->next_index[slot] > 1) l->next_index[slot] -= 1;
+    }
+}
+
 /* Candidate side: one RequestVoteRPC per slot, the candidate's own slot
  * included; elected iff a strict majority granted and no reply carried a
  * term above the candidate's. */
@@ -416,17 +434,32 @@ int orc_follower_clamp(uint64_t count, const int32_t *leader_commit,
 
 /* raft.go:142-153 for every (group, follower) slot s = p*ld + g: abdication,
  * the term gate and the prevLogIndex/prevLogTerm consistency check (direct
- * slot indexing, :151).  Follower logs are a CSR arena indexed by slot. */
+ * slot indexing, :151), then the leader's bookkeeping for the reply.  Follower
+ * logs are a CSR arena indexed by slot.  Slots outside active_mask (NULL = all
+ * n) receive no RPC and are left untouched. */
 int orc_append_check(uint32_t G, uint32_t n, uint32_t ld,
+                     const uint16_t *active_mask,
                      const int32_t *follower_term, const int32_t *leader_term,
                      const int32_t *prev_log_index, const int32_t *prev_log_term,
+                     const int32_t *n_new,
                      const uint32_t *flog_off, const int32_t *flog_term,
                      int32_t *follower_term_out, uint16_t *success_mask,
-                     uint16_t *stepdown_mask, uint8_t *status_out) {
+                     uint16_t *stepdown_mask, int32_t *match_index_io,
+                     int32_t *next_index_io, uint8_t *status_out) {
     if (n < 1 || n > ORC_MAX_SLOTS || ld < G) return -1;
     for (uint32_t g = 0; g < G; g++) {
         uint32_t ok = 0, sd = 0; uint8_t st = 0;
+        uint32_t act = active_mask ? active_mask[g] : 0xFFFFu;
+        rf_node L; memset(&L, 0, sizeof L);
+        int64_t mi[ORC_MAX_SLOTS], ni[ORC_MAX_SLOTS];
+        L.n_peers = n; L.match_index = mi; L.next_index = ni;
         for (uint32_t p = 0; p < n; p++) {
+            size_t s = (size_t)p * ld + g;
+            mi[p] = match_index_io ? match_index_io[s] : 0;
+            ni[p] = next_index_io ? next_index_io[s] : 1;
+        }
+        for (uint32_t p = 0; p < n; p++) {
+            if (!(act >> p & 1)) continue;
             size_t s = (size_t)p * ld + g;
             int64_t len = (int64_t)flog_off[s + 1] - (int64_t)flog_off[s];
             rf_entry stack_log[64];
@@ -443,7 +476,14 @@ int orc_append_check(uint32_t G, uint32_t n, uint32_t ld,
             if (leader_term[g] > before) sd |= 1u << p;
             if (success) ok |= 1u << p;
             follower_term_out[s] = (int32_t)f.current_term;
+            rf_leader_on_append_reply(&L, p, success, leader_term[g] >= before,
+                                      prev_log_index[s], n_new ? n_new[s] : 0);
             if (f.log != stack_log) free(f.log);
+        }
+        for (uint32_t p = 0; p < n; p++) {
+            size_t s = (size_t)p * ld + g;
+            if (match_index_io) match_index_io[s] = (int32_t)mi[p];
+            if (next_index_io) next_index_io[s] = (int32_t)ni[p];
         }
         success_mask[g] = (uint16_t)ok; stepdown_mask[g] = (uint16_t)sd;
         if (status_out) status_out[g] = st;

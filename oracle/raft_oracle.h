@@ -82,6 +82,9 @@ void rf_log_append(rf_node *n, const rf_entry *e, int64_t count);
  * (state: raft.go:48-51, 65-68, 114-117; rule: Raft paper Fig. 2). */
 int64_t rf_quorum_match_index(const int64_t *match, int64_t n);
 int rf_leader_advance_commit(rf_node *leader);
+void rf_leader_on_append_reply(rf_node *leader, int64_t slot, int success,
+                               int reached_log_check, int64_t prev_log_index,
+                               int64_t n_new);
 int rf_candidate_tally(rf_node **voters, int64_t n, int64_t cand_term,
                        int64_t cand_id, uint32_t *grant_mask,
                        uint32_t *stepdown_mask, int64_t *max_term,
@@ -121,11 +124,14 @@ int orc_follower_clamp(uint64_t count, const int32_t *leader_commit,
                        const int32_t *commit, const int32_t *last_new_index,
                        int32_t *commit_out);             /* raft.go:172-176 */
 int orc_append_check(uint32_t G, uint32_t n, uint32_t ld,
+                     const uint16_t *active_mask,
                      const int32_t *follower_term, const int32_t *leader_term,
                      const int32_t *prev_log_index, const int32_t *prev_log_term,
+                     const int32_t *n_new,
                      const uint32_t *flog_off, const int32_t *flog_term,
                      int32_t *follower_term_out, uint16_t *success_mask,
-                     uint16_t *stepdown_mask, uint8_t *status_out); /* :142-153 */
+                     uint16_t *stepdown_mask, int32_t *match_index_io,
+                     int32_t *next_index_io, uint8_t *status_out); /* :142-153 */
 
 /* ---- CPU baseline: reference-shaped heap objects, timed ---- */
 typedef struct orc_cluster_set orc_cluster_set;

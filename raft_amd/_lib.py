@@ -39,6 +39,9 @@ PROTOTYPES = {
     "rq_vote_tally_joint": [vp, u32, u32, u32] + _MASKS + _VOTE_IN + _VOTE_OUT + [u8p],
     "rq_fused_round_joint": [vp, u32, u32, u32] + _MASKS + _COMMIT_IN + _VOTE_IN + [i32p] + _VOTE_OUT + [u8p],
     "rq_follower_clamp": [vp, u64, i32p, i32p, i32p, i32p],
+    "rq_append_check": [vp, u32, u32, u32, u16p, i32p, i32p, i32p, i32p, i32p, u32p, i32p,
+                        i32p, u16p, u16p, i32p, i32p, u8p],
+    "rq_append_check_dev": [vp, vp, u32, u32, u32] + [vp] * 15,
     "rq_upload": [vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN,
     "rq_step": [vp, u32],
     "rq_download": [vp, i32p] + _VOTE_OUT + [u8p],

@@ -26,6 +26,9 @@ struct rq_engine {
     uint8_t *elected = nullptr, *status = nullptr;
     uint32_t *log_off = nullptr;  // [ld + 1]
     int32_t *log_term = nullptr;  // [max_log_terms]
+    // grow-only scratch for entry points whose shapes the fixed buffers do not fit
+    char *aux = nullptr;
+    size_t aux_bytes = 0;
     // resident round (rq_upload / rq_step / rq_download)
     bool resident = false;
     uint32_t res_G = 0, res_n = 0;
@@ -281,6 +284,7 @@ int rq_engine_destroy(rq_engine *e) {
             if (hipStreamDestroy(e->stream) != hipSuccess) rc = RQ_E_HIP;
         }
         if (e->slab && hipFree(e->slab) != hipSuccess) rc = RQ_E_HIP;
+        if (e->aux && hipFree(e->aux) != hipSuccess) rc = RQ_E_HIP;
     }
     delete e;
     return rc;
@@ -404,6 +408,115 @@ int rq_follower_clamp(rq_engine *e, uint64_t count, const int32_t *leader_commit
                                        e->last_log_term, e->stream));
     RQ_TRY(d2h(e, commit_out, e->last_log_term, bytes));
     RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+static int append_args_ok(const rq_append_args &a) {
+    if (a.n < 1 || a.n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
+    if (!a.follower_term || !a.leader_term || !a.prev_log_index || !a.prev_log_term ||
+        !a.flog_off || !a.flog_term || !a.follower_term_out || !a.success_mask || !a.stepdown_mask)
+        return RQ_E_ARG;
+    return RQ_OK;
+}
+
+int rq_append_check(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                    const uint16_t *active_mask, const int32_t *follower_term,
+                    const int32_t *leader_term, const int32_t *prev_log_index,
+                    const int32_t *prev_log_term, const int32_t *n_new,
+                    const uint32_t *flog_off, const int32_t *flog_term,
+                    int32_t *follower_term_out, uint16_t *success_mask, uint16_t *stepdown_mask,
+                    int32_t *match_index_io, int32_t *next_index_io, uint8_t *status_out) {
+    if (!e) return RQ_E_ARG;
+    rq_append_args h;
+    std::memset(&h, 0, sizeof h);
+    h.G = G; h.ld = ld; h.n = n; h.active_mask = active_mask;
+    h.follower_term = follower_term; h.leader_term = leader_term;
+    h.prev_log_index = prev_log_index; h.prev_log_term = prev_log_term; h.n_new = n_new;
+    h.flog_off = flog_off; h.flog_term = flog_term; h.follower_term_out = follower_term_out;
+    h.success_mask = success_mask; h.stepdown_mask = stepdown_mask;
+    h.match_index_io = match_index_io; h.next_index_io = next_index_io; h.status_out = status_out;
+    RQ_TRY(append_args_ok(h));
+    if (G > e->max_groups) return RQ_E_RANGE;
+    if (G == 0) return RQ_OK;
+    const size_t slots = (size_t)n * ld;
+    for (size_t i = 0; i < slots; i++)
+        if (flog_off[i + 1] < flog_off[i]) return RQ_E_ARG;
+    const size_t arena = flog_off[slots];
+    // device image: 7 planes, offsets, arena, 2 masks (+1 input mask), status, leader terms
+    const size_t plane = up(slots * 4);
+    const size_t total = 7 * plane + up((slots + 1) * 4) + up(arena * 4 + 4) + 3 * up((size_t)G * 2) +
+                         up(G) + up((size_t)G * 4);
+    std::lock_guard<std::mutex> lk(e->mu);
+    RQ_HIP(e, hipSetDevice(e->device));
+    if (total > e->aux_bytes) {
+        if (e->aux) { RQ_HIP(e, hipFree(e->aux)); e->aux = nullptr; e->aux_bytes = 0; }
+        if (hipMalloc((void **)&e->aux, total) != hipSuccess) return RQ_E_NOMEM;
+        e->aux_bytes = total;
+    }
+    char *p = e->aux;
+    auto take = [&p](size_t bytes) { char *r = p; p += bytes; return r; };
+    int32_t *d_ft = (int32_t *)take(plane), *d_pi = (int32_t *)take(plane), *d_pt = (int32_t *)take(plane);
+    int32_t *d_nn = (int32_t *)take(plane), *d_mi = (int32_t *)take(plane), *d_ni = (int32_t *)take(plane);
+    int32_t *d_fo = (int32_t *)take(plane);
+    uint32_t *d_off = (uint32_t *)take(up((slots + 1) * 4));
+    int32_t *d_arena = (int32_t *)take(up(arena * 4 + 4));
+    uint16_t *d_act = (uint16_t *)take(up((size_t)G * 2));
+    uint16_t *d_ok = (uint16_t *)take(up((size_t)G * 2)), *d_sd = (uint16_t *)take(up((size_t)G * 2));
+    uint8_t *d_st = (uint8_t *)take(up(G));
+    int32_t *d_lt = (int32_t *)take(up((size_t)G * 4));
+    RQ_TRY(h2d(e, d_ft, follower_term, slots * 4));
+    RQ_TRY(h2d(e, d_pi, prev_log_index, slots * 4));
+    RQ_TRY(h2d(e, d_pt, prev_log_term, slots * 4));
+    if (n_new) RQ_TRY(h2d(e, d_nn, n_new, slots * 4));
+    if (match_index_io) RQ_TRY(h2d(e, d_mi, match_index_io, slots * 4));
+    if (next_index_io) RQ_TRY(h2d(e, d_ni, next_index_io, slots * 4));
+    // slots that receive no RPC keep the caller's term in the output plane
+    RQ_TRY(h2d(e, d_fo, follower_term, slots * 4));
+    RQ_TRY(h2d(e, d_off, flog_off, (slots + 1) * 4));
+    RQ_TRY(h2d(e, d_arena, flog_term, arena * 4));
+    if (active_mask) RQ_TRY(h2d(e, d_act, active_mask, (size_t)G * 2));
+    RQ_TRY(h2d(e, d_lt, leader_term, (size_t)G * 4));
+    rq_append_args a = h;
+    a.active_mask = active_mask ? d_act : nullptr;
+    a.follower_term = d_ft; a.leader_term = d_lt; a.prev_log_index = d_pi; a.prev_log_term = d_pt;
+    a.n_new = n_new ? d_nn : nullptr; a.flog_off = d_off; a.flog_term = d_arena;
+    a.follower_term_out = d_fo; a.success_mask = d_ok; a.stepdown_mask = d_sd;
+    a.match_index_io = match_index_io ? d_mi : nullptr;
+    a.next_index_io = next_index_io ? d_ni : nullptr;
+    a.status_out = d_st;
+    RQ_HIP(e, rq_launch_append_check(a, e->stream));
+    RQ_TRY(d2h(e, follower_term_out, d_fo, slots * 4));
+    RQ_TRY(d2h(e, success_mask, d_ok, (size_t)G * 2));
+    RQ_TRY(d2h(e, stepdown_mask, d_sd, (size_t)G * 2));
+    RQ_TRY(d2h(e, match_index_io, d_mi, slots * 4));
+    RQ_TRY(d2h(e, next_index_io, d_ni, slots * 4));
+    RQ_TRY(d2h(e, status_out, d_st, G));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
+                        const uint16_t *active_mask, const int32_t *follower_term,
+                        const int32_t *leader_term, const int32_t *prev_log_index,
+                        const int32_t *prev_log_term, const int32_t *n_new,
+                        const uint32_t *flog_off, const int32_t *flog_term,
+                        int32_t *follower_term_out, uint16_t *success_mask,
+                        uint16_t *stepdown_mask, int32_t *match_index_io,
+                        int32_t *next_index_io, uint8_t *status_out) {
+    if (!e) return RQ_E_ARG;
+    rq_append_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.n = n; a.active_mask = active_mask;
+    a.follower_term = follower_term; a.leader_term = leader_term;
+    a.prev_log_index = prev_log_index; a.prev_log_term = prev_log_term; a.n_new = n_new;
+    a.flog_off = flog_off; a.flog_term = flog_term; a.follower_term_out = follower_term_out;
+    a.success_mask = success_mask; a.stepdown_mask = stepdown_mask;
+    a.match_index_io = match_index_io; a.next_index_io = next_index_io; a.status_out = status_out;
+    RQ_TRY(append_args_ok(a));
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipError_t err = rq_launch_append_check(a, (hipStream_t)stream);
+    if (err == hipErrorInvalidValue) return RQ_E_ARG;
+    RQ_HIP(e, err);
     return RQ_OK;
 }
 

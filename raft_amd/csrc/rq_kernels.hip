@@ -608,6 +608,82 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args a) {
     }
 }
 
+// ---------------------------------------------------------------------------
+// AppendEntries consistency batch: one thread per group, slots in chunks of 4
+// whose loads are all issued before the dependent log gathers.
+//   stepdown : term > cur, cur' = max(cur, term)                 (raft.go:142, :219-221)
+//   reach    : !(term < cur')                                    (:145-147)
+//   success  : reach && log[prevLogIndex].TermNum == prevLogTerm (:151-153)
+//   prevLogIndex outside the follower's log is an index panic in Go: status
+//   bit, no success.
+// Leader bookkeeping for the reply (Raft Fig. 2; the reference only declares
+// nextIndex/matchIndex, raft.go:60-68): success -> match = prev + n_new,
+// next = match + 1; rejected at the log check -> next = max(next - 1, 1);
+// rejected for a stale term -> unchanged.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args a) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.G) return;
+    constexpr int C = 4;
+    const size_t ld = a.ld;
+    const uint32_t n = a.n;
+    const int32_t lt = __builtin_nontemporal_load(a.leader_term + g);
+    uint32_t act = a.active_mask ? (uint32_t)a.active_mask[g] : 0xFFFFu;
+    act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
+    uint32_t ok = 0, sd = 0, st = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += C) {
+        int32_t ft[C], pi[C], pt[C], nn[C], mi[C], ni[C], tg[C];
+        uint32_t o0[C], o1[C];
+        bool live[C];
+#pragma unroll
+        for (int q = 0; q < C; q++) {
+            const uint32_t p = c0 + q;
+            live[q] = p < n && ((act >> p) & 1u);
+            ft[q] = pi[q] = pt[q] = nn[q] = mi[q] = 0; ni[q] = 1; o0[q] = o1[q] = 0;
+            if (live[q]) {
+                const size_t s = p * ld + g;
+                ft[q] = __builtin_nontemporal_load(a.follower_term + s);
+                pi[q] = __builtin_nontemporal_load(a.prev_log_index + s);
+                pt[q] = __builtin_nontemporal_load(a.prev_log_term + s);
+                o0[q] = __builtin_nontemporal_load(a.flog_off + s);
+                o1[q] = a.flog_off[s + 1];
+                if (a.n_new) nn[q] = __builtin_nontemporal_load(a.n_new + s);
+                if (a.match_index_io) mi[q] = __builtin_nontemporal_load(a.match_index_io + s);
+                if (a.next_index_io) ni[q] = __builtin_nontemporal_load(a.next_index_io + s);
+            }
+        }
+        bool reach[C], inb[C];
+#pragma unroll
+        for (int q = 0; q < C; q++) {
+            reach[q] = live[q] && lt >= ft[q];
+            inb[q] = (uint32_t)pi[q] < (o1[q] - o0[q]);
+            tg[q] = 0;
+            if (reach[q] && inb[q]) tg[q] = a.flog_term[(size_t)o0[q] + (uint32_t)pi[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < C; q++) {
+            if (!live[q]) continue;
+            const uint32_t p = c0 + q;
+            const size_t s = p * ld + g;
+            const bool success = reach[q] && inb[q] && tg[q] == pt[q];
+            sd |= (uint32_t)(lt > ft[q]) << p;
+            ok |= (uint32_t)success << p;
+            st |= (reach[q] && !inb[q]) ? kStLogOob : 0;
+            __builtin_nontemporal_store(max(ft[q], lt), a.follower_term_out + s);
+            if (a.match_index_io || a.next_index_io) {
+                int32_t m2 = mi[q], n2 = ni[q];
+                if (success) { m2 = (int32_t)((uint32_t)pi[q] + (uint32_t)nn[q]); n2 = (int32_t)((uint32_t)m2 + 1u); }
+                else if (reach[q]) { n2 = n2 > 1 ? n2 - 1 : 1; }
+                if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
+                if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
+            }
+        }
+    }
+    a.success_mask[g] = (uint16_t)ok;
+    a.stepdown_mask[g] = (uint16_t)sd;
+    if (a.status_out) a.status_out[g] = (uint8_t)st;
+}
+
 // raft.go:172-176 elementwise
 __global__ __launch_bounds__(kBlock) void rq_follower_clamp_kernel(
         uint64_t count, const int32_t *lc, const int32_t *ci, const int32_t *ln,
@@ -780,6 +856,15 @@ hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, in
     const int v = pick_v(b, want, what);
     if (b.m <= 8) return launch_joint_what<8>(b, what, v, flags, block, stream);
     return launch_joint_what<16>(b, what, v, flags, block, stream);
+}
+
+hipError_t rq_launch_append_check(const rq_append_args &a, hipStream_t stream) {
+    if (a.G == 0) return hipSuccess;
+    if (a.G > 0x7FFFFFFFu || a.ld < a.G || a.n < 1 || a.n > 16) return hipErrorInvalidValue;
+    const uint32_t block = 128;
+    const uint32_t grid = (a.G + block - 1) / block;
+    hipLaunchKernelGGL(rq_append_check_kernel, dim3(grid), dim3(block), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,

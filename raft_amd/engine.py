@@ -203,6 +203,36 @@ class QuorumEngine:
                                               _p(ln, i32p), _p(out, i32p)), "rq_follower_clamp")
         return out
 
+    def append_check(self, follower_term, leader_term, prev_log_index, prev_log_term,
+                     flog_off, flog_term, n_new=None, match_index=None, next_index=None,
+                     active_mask=None, G=None):
+        """AppendEntries consistency batch.  Returns a dict with follower_term,
+        success_mask, stepdown_mask, status and (if given) updated match_index /
+        next_index copies."""
+        ft = _plane(follower_term, "follower_term")
+        n, ld = ft.shape
+        G = ld if G is None else G
+        pi = _plane(prev_log_index, "prev_log_index"); pt = _plane(prev_log_term, "prev_log_term")
+        lt = _vec(leader_term, np.int32, "leader_term", G)
+        off = _vec(flog_off, np.uint32, "flog_off", n * ld + 1)
+        arena = np.ascontiguousarray(flog_term, dtype=np.int32)
+        if arena.size == 0:
+            arena = np.zeros(1, np.int32)
+        opt = lambda a, name: None if a is None else _plane(a, name).copy()
+        nn, mi, ni = opt(n_new, "n_new"), opt(match_index, "match_index"), opt(next_index, "next_index")
+        am = None if active_mask is None else _vec(active_mask, np.uint16, "active_mask", G)
+        out = dict(follower_term=ft.copy(), success_mask=np.zeros(G, np.uint16),
+                   stepdown_mask=np.zeros(G, np.uint16), status=np.zeros(G, np.uint8),
+                   match_index=mi, next_index=ni)
+        pp = lambda a, t: None if a is None else _p(a, t)
+        rc = self._l.rq_append_check(self._h, G, n, ld, pp(am, u16p), _p(ft, i32p), _p(lt, i32p),
+                                     _p(pi, i32p), _p(pt, i32p), pp(nn, i32p), _p(off, u32p),
+                                     _p(arena, i32p), _p(out["follower_term"], i32p),
+                                     _p(out["success_mask"], u16p), _p(out["stepdown_mask"], u16p),
+                                     pp(mi, i32p), pp(ni, i32p), _p(out["status"], u8p))
+        self._check(rc, "rq_append_check")
+        return out
+
     # -- device-resident trio ----------------------------------------------
     def upload(self, match, commit, leader_term, log_off, log_term,
                voter_term, voted_for, last_log_term, cand_term, cand_id, G=None):

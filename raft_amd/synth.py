@@ -248,3 +248,46 @@ def gen_adversarial(G, n, seed=DEFAULT_SEED, ld=None):
     return Batch(G=G, n=n, ld=ld, match=match, commit=commit, leader_term=leader_term,
                  log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
                  last_log_term=ll, cand_term=cand_term, cand_id=cand_id)
+
+
+def gen_append(G, n, seed=DEFAULT_SEED, ld=None, max_len=12, adversarial=False):
+    """AppendEntries consistency batch: per (slot, group) follower logs in one
+    CSR arena indexed by slot id s = p*ld + g, a leader term per group, and for
+    every follower prevLogIndex / prevLogTerm / number of new entries plus the
+    leader's matchIndex / nextIndex.  About 60% of the checks succeed; with
+    adversarial=True indices outside the log, empty logs and stale leaders are
+    frequent."""
+    ld = G if ld is None else ld
+    slots = n * ld
+    sidx = np.arange(slots, dtype=np.int64)
+    g_of = sidx % ld
+    valid = g_of < G
+    lens = np.where(valid, (0 if adversarial else 1) + _below(seed, F_LOGLEN, sidx, max_len), 0)
+    off = _csr(lens)
+    total = int(off[-1])
+    grp = np.repeat(sidx, lens)
+    pos = np.arange(total, dtype=np.int64) - off[:-1].astype(np.int64)[grp]
+    T = 1 + _below(seed, F_LOGT, sidx, 6)
+    flog = (1 + (pos * T[grp]) // np.maximum(lens[grp], 1)).astype(np.int32)
+    lt = (3 + _below(seed, F_LTERM, np.arange(G), 6)).astype(np.int32)
+    u = _unit(seed, F_VTERM, sidx)
+    lt_s = np.where(valid, lt[np.minimum(g_of, G - 1)], 0).astype(np.int64)
+    ft = lt_s + np.where(u < 0.5, -1, np.where(u < 0.9, 0, 1))
+    span = np.maximum(lens, 1) + (3 if adversarial else 0)
+    pi = _below(seed, F_MATCH, sidx, span) - (1 if adversarial else 0)
+    inb = (pi >= 0) & (pi < lens)
+    t_at = np.where(inb, flog[np.minimum(off[:-1].astype(np.int64) + np.clip(pi, 0, None), max(total - 1, 0))]
+                    if total else 0, 0)
+    pt = np.where(_unit(seed, F_AUX, sidx) < 0.75, t_at, t_at + 1)
+    nn = _below(seed, F_AUX2, sidx, 4)
+    mi = _below(seed, F_COMMIT, sidx, 8)
+    ni = 1 + _below(seed, F_CID, sidx, 9)
+    shape = (n, ld)
+    act = ((1 << n) - 1) & ~(1 << _below(seed, F_CTERM, np.arange(G), n))     # the leader's own slot gets no RPC
+    if adversarial:
+        act = _below(seed, F_JOINT, np.arange(G), 1 << n)
+    return Batch(G=G, n=n, ld=ld, follower_term=ft.astype(np.int32).reshape(shape), leader_term=lt,
+                 prev_log_index=pi.astype(np.int32).reshape(shape), prev_log_term=pt.astype(np.int32).reshape(shape),
+                 n_new=nn.astype(np.int32).reshape(shape), flog_off=off, flog_term=flog,
+                 match_index=mi.astype(np.int32).reshape(shape), next_index=ni.astype(np.int32).reshape(shape),
+                 active_mask=act.astype(np.uint16))

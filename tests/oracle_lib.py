@@ -72,8 +72,8 @@ def lib():
         l.orc_vote_tally_joint.argtypes = [u32, u32, u32, u16p, u16p, i32p, i32p, i32p, i32p, i32p,
                                            i32p, u16p, u16p, u8p, i32p, u8p]
         l.orc_follower_clamp.argtypes = [C.c_uint64, i32p, i32p, i32p, i32p]
-        l.orc_append_check.argtypes = [u32, u32, u32, i32p, i32p, i32p, i32p, u32p, i32p, i32p,
-                                       u16p, u16p, u8p]
+        l.orc_append_check.argtypes = [u32, u32, u32, u16p, i32p, i32p, i32p, i32p, i32p, u32p, i32p,
+                                       i32p, u16p, u16p, i32p, i32p, u8p]
         l.orc_bench_build.argtypes = [u32, u32, u32, i32p, i32p, i32p, u32p, i32p, i32p, i32p, i32p,
                                       i32p, i32p]
         l.orc_bench_build.restype = C.c_void_p
@@ -147,6 +147,29 @@ def follower_clamp(leader_commit, commit, last_new_index):
     ln = _c(last_new_index, np.int32).ravel()
     out = np.zeros(lc.size, np.int32)
     assert lib().orc_follower_clamp(lc.size, _p(lc, i32p), _p(ci, i32p), _p(ln, i32p), _p(out, i32p)) == 0
+    return out
+
+
+def append_check(follower_term, leader_term, prev_log_index, prev_log_term, flog_off, flog_term,
+                 n_new=None, match_index=None, next_index=None, active_mask=None, G=None):
+    ft = _c(follower_term, np.int32); n, ld = ft.shape; G = ld if G is None else G
+    pi = _c(prev_log_index, np.int32); pt = _c(prev_log_term, np.int32); lt = _c(leader_term, np.int32)
+    off = _c(flog_off, np.uint32); arena = _c(flog_term, np.int32)
+    if arena.size == 0:
+        arena = np.zeros(1, np.int32)
+    opt = lambda a: None if a is None else _c(a, np.int32).copy()
+    nn, mi, ni = opt(n_new), opt(match_index), opt(next_index)
+    am = None if active_mask is None else _c(active_mask, np.uint16)
+    out = Result(follower_term=ft.copy(), success_mask=np.zeros(G, np.uint16),
+                 stepdown_mask=np.zeros(G, np.uint16), status=np.zeros(G, np.uint8),
+                 match_index=mi, next_index=ni)
+    pp = lambda a, t: None if a is None else _p(a, t)
+    rc = lib().orc_append_check(G, n, ld, pp(am, u16p), _p(ft, i32p), _p(lt, i32p), _p(pi, i32p),
+                                _p(pt, i32p), pp(nn, i32p), _p(off, u32p), _p(arena, i32p),
+                                _p(out.follower_term, i32p), _p(out.success_mask, u16p),
+                                _p(out.stepdown_mask, u16p), pp(mi, i32p), pp(ni, i32p),
+                                _p(out.status, u8p))
+    assert rc == 0, rc
     return out
 
 

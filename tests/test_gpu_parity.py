@@ -305,3 +305,61 @@ def test_full_size_1m_by_5(engine):
     perm = np.array([3, 0, 4, 1, 2])
     c2, _ = engine.commit_advance(b.match[perm], b.commit, b.leader_term, b.log_off, b.log_term)
     assert np.array_equal(c2, got.commit)
+
+
+# ---------------------------------------------------------------------------
+# AppendEntries consistency batch (raft.go:142-153) + leader reply bookkeeping
+# ---------------------------------------------------------------------------
+def _append_args(b, full=True):
+    kw = dict(n_new=b.n_new, match_index=b.match_index, next_index=b.next_index,
+              active_mask=b.active_mask, G=b.G) if full else dict(G=b.G)
+    return (b.follower_term, b.leader_term, b.prev_log_index, b.prev_log_term, b.flog_off, b.flog_term), kw
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 9, 16])
+def test_append_check(engine, n):
+    for G, ld in ((1, 1), (65, 68), (5000, 5000), (30011, 30080)):
+        for adv in (False, True):
+            b = synth.gen_append(G, n, seed=7 * n + G, ld=ld, adversarial=adv)
+            for full in (True, False):
+                args, kw = _append_args(b, full)
+                got = engine.append_check(*args, **kw)
+                exp = o.append_check(*args, **kw)
+                for f in ("follower_term", "success_mask", "stepdown_mask", "status"):
+                    assert np.array_equal(got[f][..., :G], exp[f][..., :G]), (f, n, G, adv, full)
+                if full:
+                    assert np.array_equal(got["match_index"][:, :G], exp["match_index"][:, :G])
+                    assert np.array_equal(got["next_index"][:, :G], exp["next_index"][:, :G])
+
+
+def test_append_check_kat(engine):
+    n, G = 4, 1
+    flog_off = np.arange(0, 2 * n + 1, 2, dtype=np.uint32)
+    flog = np.tile(np.array([0, 1], np.int32), n)
+    ft = np.array([[3], [1], [1], [0]], np.int32)
+    pi = np.array([[1], [1], [1], [2]], np.int32)
+    pt = np.array([[1], [2], [1], [1]], np.int32)
+    nn = np.array([[1], [1], [2], [1]], np.int32)
+    mi = np.zeros((n, G), np.int32); ni = np.full((n, G), 3, np.int32)
+    r = engine.append_check(ft, [2], pi, pt, flog_off, flog, n_new=nn, match_index=mi, next_index=ni)
+    assert r["success_mask"][0] == 0b0100 and r["stepdown_mask"][0] == 0b1110
+    assert r["follower_term"][:, 0].tolist() == [3, 2, 2, 2] and r["status"][0] == 1
+    assert r["match_index"][:, 0].tolist() == [0, 0, 3, 0]
+    assert r["next_index"][:, 0].tolist() == [3, 2, 4, 2]
+
+
+def test_replicate_then_commit_closes_the_loop(engine):
+    """append_check updates matchIndex on the device; feeding it to
+    commit_advance reproduces the oracle's leader state after one replication
+    round: replicate -> match -> commit, all through the C-ABI."""
+    G, n = 20000, 5
+    b = synth.gen_append(G, n, seed=99)
+    args, kw = _append_args(b)
+    got = engine.append_check(*args, **kw)
+    exp = o.append_check(*args, **kw)
+    c = synth.gen_fused(G, n, seed=5)
+    for side in (got, exp):
+        side["commit"] = None
+    gc, gst = engine.commit_advance(got["match_index"], c.commit, c.leader_term, c.log_off, c.log_term)
+    ec, est = o.commit_advance(exp["match_index"], c.commit, c.leader_term, c.log_off, c.log_term)
+    assert np.array_equal(gc, ec) and np.array_equal(gst, est)

@@ -315,3 +315,30 @@ def test_batch_oracle_equals_numpy_closed_form():
         assert np.array_equal(r.commit, exp.astype(np.int32))
         st = np.where(adv & ~inb, 1, 0) | np.where((reach & empty).any(0), 2, 0)
         assert np.array_equal(r.status, st.astype(np.uint8))
+
+
+def test_append_check_batch_semantics():
+    """Hand-checked (group, follower) cases for the AppendEntries consistency
+    batch: A2 (stale leader, raft.go:145-147), A3 (term mismatch, :151-153), a
+    success, and an out-of-range prevLogIndex (:151 index panic)."""
+    # one group, four follower slots, each with log terms [0, 1] (sentinel + one entry)
+    n, G = 4, 1
+    flog_off = np.arange(0, 2 * n + 1, 2, dtype=np.uint32)
+    flog = np.tile(np.array([0, 1], np.int32), n)
+    ft = np.array([[3], [1], [1], [0]], np.int32)        # follower terms
+    pi = np.array([[1], [1], [1], [2]], np.int32)        # prevLogIndex
+    pt = np.array([[1], [2], [1], [1]], np.int32)        # prevLogTerm
+    nn = np.array([[1], [1], [2], [1]], np.int32)
+    mi = np.zeros((n, G), np.int32); ni = np.full((n, G), 3, np.int32)
+    r = o.append_check(ft, [2], pi, pt, flog_off, flog, n_new=nn, match_index=mi, next_index=ni)
+    assert r.success_mask[0] == 0b0100                   # only slot 2 passes
+    assert r.stepdown_mask[0] == 0b1110                  # term 2 > 1, 1, 0
+    assert r.follower_term[:, 0].tolist() == [3, 2, 2, 2]
+    assert r.status[0] == o.ST_LOG_OOB                   # slot 3: prevLogIndex 2 >= len 2
+    assert r.match_index[:, 0].tolist() == [0, 0, 3, 0]  # success: prev + n_new
+    assert r.next_index[:, 0].tolist() == [3, 2, 4, 2]   # stale: unchanged; mismatch/oob: back off
+    # active_mask: slots outside it are untouched
+    r = o.append_check(ft, [2], pi, pt, flog_off, flog, n_new=nn, match_index=mi, next_index=ni,
+                       active_mask=[0b0100])
+    assert r.follower_term[:, 0].tolist() == [3, 1, 2, 0] and r.success_mask[0] == 0b0100
+    assert r.next_index[:, 0].tolist() == [3, 3, 4, 3] and r.status[0] == 0
