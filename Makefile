@@ -6,7 +6,7 @@ ARCH    ?= gfx950
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC     = raft_amd/csrc
 
-all: raft_amd/librq.so oracle/librq_oracle.so
+all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h include/rq.h
 	@mkdir -p build
@@ -15,10 +15,15 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h include/rq.h
 raft_amd/librq.so: build/rq_kernels.o build/rq_engine.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -o $@
 
+HOST = $(CSRC)/host
+raft_amd/libraft_host.so: $(HOST)/raft_host.cpp $(HOST)/raft_host_capi.cpp $(HOST)/raft_host.hpp include/rq.h raft_amd/librq.so
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Wextra $(HOST)/raft_host.cpp $(HOST)/raft_host_capi.cpp \
+	    -Lraft_amd -lrq -Wl,-rpath,'$$ORIGIN' -o $@
+
 oracle/librq_oracle.so: oracle/raft_oracle.c oracle/raft_oracle.h
 	$(CC) -O2 -std=c11 -fPIC -shared -Wall -Wextra -pthread $< -o $@
 
 clean:
-	rm -rf build raft_amd/librq.so oracle/librq_oracle.so
+	rm -rf build raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so
 
 .PHONY: all clean

@@ -1,0 +1,195 @@
+// raft_host.cpp -- see raft_host.hpp.
+#include "raft_host.hpp"
+
+#include <climits>
+
+#include "../../../include/rq.h"
+
+namespace raft {
+
+int64_t minInt(int64_t a, int64_t b) { return a < b ? a : b; }
+
+const Entry &lastEntry(const std::vector<Entry> &e) {
+    if (e.empty()) throw GoPanic("index out of range [-1]");
+    return e.back();
+}
+
+Node *NewNode(int64_t id, std::vector<Node *> peers, std::function<void(const std::string &)> statemachine) {
+    Node *n = new Node();
+    n->id = id;
+    n->stateMachine = std::move(statemachine);
+    n->nodeType = Follower;
+    n->votedFor = -1;
+    peers.push_back(n);  // raft.go:94
+    for (Node *member : peers) member->peers = peers;  // raft.go:95-97
+    return n;
+}
+
+void Node::BecomeLeader() {
+    nodeType = Leader;
+    nextIndex.assign(peers.size(), (int64_t)log.size() + 1);  // raft.go:106-109
+    matchIndex.assign(peers.size(), 0);                       // raft.go:114-117
+    leaderArrays = true;
+}
+
+void Node::BecomeFollower() {
+    nodeType = Follower;
+    nextIndex.clear(); matchIndex.clear(); leaderArrays = false;
+}
+
+void Node::BecomeCandidate() {
+    nodeType = Candidate;
+    nextIndex.clear(); matchIndex.clear(); leaderArrays = false;
+}
+
+void Node::testToAbdicateLeadership(int64_t term) {
+    if (term > currentTerm) {
+        currentTerm = term;
+        nodeType = Follower;
+    }
+}
+
+std::pair<int64_t, bool> Node::RequestVoteRPC(int64_t term, int64_t candidateId, int64_t, int64_t) {
+    testToAbdicateLeadership(term);                       // :187
+    if (term < currentTerm) return {currentTerm, false};  // :190-192
+    const bool notYetVoted = votedFor == -1;              // :202
+    const bool votedSameBefore = votedFor == candidateId; // :203
+    const bool requesterMoreUpToDate = lastEntry(log).TermNum <= term;  // :204
+    return {currentTerm, (notYetVoted || votedSameBefore) && requesterMoreUpToDate};
+}
+
+std::pair<int64_t, bool> Node::AppendEntriesRPC(int64_t term, int64_t, int64_t prevLogIndex,
+                                                int64_t prevLogTerm, const std::vector<Entry> &newEntries,
+                                                int64_t leaderCommit) {
+    testToAbdicateLeadership(term);                       // :142
+    if (term < currentTerm) return {currentTerm, false};  // :145-147
+    if (prevLogIndex < 0 || prevLogIndex >= (int64_t)log.size()) throw GoPanic("index out of range");
+    if (log[(size_t)prevLogIndex].TermNum != prevLogTerm) return {currentTerm, false};  // :151-153
+    for (const Entry &e : newEntries) {                   // :158-167
+        const bool indexIsInRange = (int64_t)log.size() <= e.Index;  // :159, inverted in the reference
+        if (indexIsInRange) throw GoPanic("index out of range");     // :161 indexes log[e.Index]
+    }
+    log.insert(log.end(), newEntries.begin(), newEntries.end());     // :170
+    if (leaderCommit > commitIndex)                                  // :174
+        commitIndex = minInt(leaderCommit, lastEntry(newEntries).Index);
+    return {currentTerm, true};
+}
+
+Node::State Node::Inspect() const {
+    return State{id, (int64_t)nodeType, currentTerm, votedFor, (int64_t)log.size(), commitIndex,
+                 lastApplied, (int64_t)peers.size(), leaderArrays};
+}
+
+void Node::SeedForTest(int64_t term, int64_t voted, NodeType type, int64_t commit) {
+    currentTerm = term; votedFor = voted; nodeType = type; commitIndex = commit;
+}
+
+void Node::SeedLogForTest(const std::vector<int64_t> &terms) {
+    log.clear();
+    for (size_t i = 0; i < terms.size(); i++) log.push_back(Entry{"", (int64_t)i, terms[i]});
+}
+
+// ---- batched driver ---------------------------------------------------------
+
+static bool narrow(int64_t v, int32_t &out) {
+    if (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX) return false;  // INT32_MIN is RQ_LOG_EMPTY
+    out = (int32_t)v;
+    return true;
+}
+
+int BatchedDriver::Flatten(RoundBuffers &b) const {
+    const uint32_t G = (uint32_t)groups_.size(), n = slots_;
+    b = RoundBuffers();
+    b.groups = G; b.slots = n; b.ld = G;
+    const size_t plane = (size_t)n * G;
+    b.match.assign(plane, 0); b.voterTerm.assign(plane, 0); b.votedFor.assign(plane, -1);
+    b.lastLogTerm.assign(plane, RQ_LOG_EMPTY); b.voterTermOut.assign(plane, 0);
+    b.commit.assign(G, INT32_MAX);          // no leader: N > commit is never true
+    b.leaderTerm.assign(G, 0);
+    b.candTerm.assign(G, INT32_MIN + 1);    // no candidate: below every term, nobody reacts
+    b.candId.assign(G, -1);
+    b.commitOut.assign(G, 0); b.maxTerm.assign(G, 0);
+    b.grantMask.assign(G, 0); b.stepdownMask.assign(G, 0);
+    b.elected.assign(G, 0); b.status.assign(G, 0);
+    b.logOff.assign((size_t)G + 1, 0);
+    for (uint32_t g = 0; g < G; g++) {
+        const Group &grp = groups_[g];
+        if (grp.Members.size() != n) return kDriverShape;
+        if (const Node *l = grp.Leader) {
+            if (!narrow(l->commitIndex, b.commit[g]) || !narrow(l->currentTerm, b.leaderTerm[g])) return kDriverRange;
+            for (uint32_t p = 0; p < n && p < l->matchIndex.size(); p++)
+                if (!narrow(l->matchIndex[p], b.match[(size_t)p * G + g])) return kDriverRange;
+            for (const Entry &e : l->log) {
+                int32_t t;
+                if (!narrow(e.TermNum, t)) return kDriverRange;
+                b.logTerm.push_back(t);
+            }
+        }
+        if (b.logTerm.size() > 0xFFFFFFFFull) return kDriverRange;
+        b.logOff[g + 1] = (uint32_t)b.logTerm.size();
+        if (const Node *c = grp.Candidate) {
+            if (!narrow(c->currentTerm, b.candTerm[g]) || !narrow(c->id, b.candId[g])) return kDriverRange;
+        }
+        for (uint32_t p = 0; p < n; p++) {
+            const Node *m = grp.Members[p];
+            const size_t i = (size_t)p * G + g;
+            if (!narrow(m->currentTerm, b.voterTerm[i]) || !narrow(m->votedFor, b.votedFor[i])) return kDriverRange;
+            if (!m->log.empty() && !narrow(m->log.back().TermNum, b.lastLogTerm[i])) return kDriverRange;
+        }
+    }
+    if (b.logTerm.empty()) b.logTerm.push_back(0);
+    return kDriverOk;
+}
+
+void BatchedDriver::Apply(const RoundBuffers &b) {
+    const uint32_t G = b.groups;
+    for (uint32_t g = 0; g < G; g++) {
+        Group &grp = groups_[g];
+        Node *leader_before = grp.Leader;
+        if (grp.Candidate) {
+            for (uint32_t p = 0; p < b.slots; p++) {
+                Node *m = grp.Members[p];
+                m->currentTerm = b.voterTermOut[(size_t)p * b.ld + g];
+                if ((b.stepdownMask[g] >> p) & 1u) m->nodeType = Follower;  // raft.go:221
+            }
+            if (b.elected[g]) {
+                grp.Candidate->BecomeLeader();
+                grp.Leader = grp.Candidate;
+                grp.Candidate = nullptr;
+            }
+        }
+        if (leader_before) leader_before->commitIndex = b.commitOut[g];
+    }
+}
+
+BatchedDriver::~BatchedDriver() {
+    if (engine_) rq_engine_destroy(engine_);
+}
+
+int BatchedDriver::Step(int device) {
+    RoundBuffers b;
+    int rc = Flatten(b);
+    if (rc != kDriverOk) return rc == kDriverRange ? RQ_E_RANGE : RQ_E_ARG;
+    const uint64_t need = b.logTerm.size();
+    if (engine_ && (engine_device_ != device || need > engine_log_cap_ || b.groups > engine_groups_)) {
+        rq_engine_destroy(engine_);
+        engine_ = nullptr;
+    }
+    if (!engine_) {
+        engine_log_cap_ = need * 2 + 4096;              // room for the leaders' logs to grow
+        engine_groups_ = b.groups ? b.groups : 1;
+        rc = rq_engine_create(device, engine_groups_, b.slots, engine_log_cap_, &engine_);
+        if (rc != RQ_OK) { engine_ = nullptr; return rc; }
+        engine_device_ = device;
+    }
+    rc = rq_fused_round(engine_, b.groups, b.slots, b.ld, b.match.data(), b.commit.data(),
+                        b.leaderTerm.data(), b.logOff.data(), b.logTerm.data(), b.voterTerm.data(),
+                        b.votedFor.data(), b.lastLogTerm.data(), b.candTerm.data(), b.candId.data(),
+                        b.commitOut.data(), b.voterTermOut.data(), b.grantMask.data(),
+                        b.stepdownMask.data(), b.elected.data(), b.maxTerm.data(), b.status.data());
+    if (rc != RQ_OK) return rc;
+    Apply(b);
+    return RQ_OK;
+}
+
+}  // namespace raft

@@ -1,0 +1,130 @@
+// raft_host.hpp -- C++ mirror of the reference's Go surface (package raft in
+// tawawhite/raft raft.go) plus the batched driver that calls librq.so.
+//
+// The build image has no Go toolchain, so the host side that a Go maintainer
+// would write (go/raft/*.go) is mirrored here in compiled, tested C++ with the
+// same names, argument meaning and error behaviour: a Go runtime panic
+// (slice index out of range) is a raft::GoPanic exception.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct rq_engine;
+
+namespace raft {
+
+// raft.go:7-13 -- iota: Leader is the zero value.
+enum NodeType : int64_t { Leader = 0, Follower = 1, Candidate = 2 };
+
+// raft.go:71-75
+struct Entry {
+    std::string Command;
+    int64_t Index = 0;
+    int64_t TermNum = 0;
+};
+
+struct GoPanic : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+class BatchedDriver;
+
+// raft.go:15-69.  Fields are private like the reference's unexported fields;
+// the batched driver is a friend the way it is a package member in Go.
+class Node {
+public:
+    void BecomeLeader();     // raft.go:101-118
+    void BecomeFollower();   // raft.go:120-124
+    void BecomeCandidate();  // raft.go:126-130
+    // raft.go:132-179
+    std::pair<int64_t, bool> AppendEntriesRPC(int64_t term, int64_t leaderId, int64_t prevLogIndex,
+                                              int64_t prevLogTerm, const std::vector<Entry> &newEntries,
+                                              int64_t leaderCommit);
+    // raft.go:181-210
+    std::pair<int64_t, bool> RequestVoteRPC(int64_t term, int64_t candidateId, int64_t lastLogIndex,
+                                            int64_t lastLogTerm);
+
+    // test access (the Go tests would sit inside the package)
+    struct State {
+        int64_t id, nodeType, currentTerm, votedFor, logLen, commitIndex, lastApplied, nPeers;
+        bool hasLeaderArrays;
+    };
+    State Inspect() const;
+    const std::vector<int64_t> &NextIndex() const { return nextIndex; }
+    const std::vector<int64_t> &MatchIndex() const { return matchIndex; }
+    std::vector<int64_t> &MatchIndexForTest() { return matchIndex; }
+    void SeedForTest(int64_t currentTerm, int64_t votedFor, NodeType type, int64_t commitIndex);
+    void SeedLogForTest(const std::vector<int64_t> &terms);
+
+private:
+    friend Node *NewNode(int64_t, std::vector<Node *>, std::function<void(const std::string &)>);
+    friend class BatchedDriver;
+    void testToAbdicateLeadership(int64_t term);  // raft.go:212-223
+
+    int64_t id = 0;
+    NodeType nodeType = Follower;
+    std::function<void(const std::string &)> stateMachine;
+    std::vector<Node *> peers;  // includes this node (raft.go:94-97)
+    int64_t currentTerm = 0;
+    int64_t votedFor = -1;
+    std::vector<Entry> log;
+    int64_t commitIndex = 0;
+    int64_t lastApplied = 0;
+    std::vector<int64_t> nextIndex;
+    std::vector<int64_t> matchIndex;
+    bool leaderArrays = false;  // Go: nextIndex/matchIndex != nil
+};
+
+// raft.go:77-99
+Node *NewNode(int64_t id, std::vector<Node *> peers, std::function<void(const std::string &)> statemachine);
+int64_t minInt(int64_t a, int64_t b);                 // raft.go:226-231
+const Entry &lastEntry(const std::vector<Entry> &e);  // raft.go:234-236, GoPanic on empty
+
+// ---- batched driver (no counterpart in the reference) ----------------------
+
+struct Group {
+    std::vector<Node *> Members;  // slot order
+    Node *Leader = nullptr;       // member currently leading, or null
+    Node *Candidate = nullptr;    // member currently asking for votes, or null
+};
+
+// Structure-of-arrays image of all groups, layout of include/rq.h.
+struct RoundBuffers {
+    uint32_t groups = 0, slots = 0, ld = 0;
+    std::vector<int32_t> match, commit, leaderTerm, logTerm;
+    std::vector<uint32_t> logOff;
+    std::vector<int32_t> voterTerm, votedFor, lastLogTerm, candTerm, candId;
+    std::vector<int32_t> commitOut, voterTermOut, maxTerm;
+    std::vector<uint16_t> grantMask, stepdownMask;
+    std::vector<uint8_t> elected, status;
+};
+
+enum : int { kDriverOk = 0, kDriverRange = -2, kDriverShape = -1 };
+
+class BatchedDriver {
+public:
+    BatchedDriver(std::vector<Group> groups, uint32_t slots) : groups_(std::move(groups)), slots_(slots) {}
+    ~BatchedDriver();
+    // AoS -> SoA.  Values outside int32 give kDriverRange and leave `b` unspecified.
+    int Flatten(RoundBuffers &b) const;
+    // Applies one round's outputs to the objects: voter terms and roles
+    // (raft.go:219-221), leader commitIndex, BecomeLeader for winners.
+    void Apply(const RoundBuffers &b);
+    // Flatten -> rq_fused_round on `device` -> Apply.  Returns an RQ_* code.
+    int Step(int device);
+    std::vector<Group> &Groups() { return groups_; }
+
+private:
+    std::vector<Group> groups_;
+    uint32_t slots_;
+    rq_engine *engine_ = nullptr;
+    int engine_device_ = -1;
+    uint64_t engine_log_cap_ = 0;
+    uint32_t engine_groups_ = 0;
+};
+
+}  // namespace raft

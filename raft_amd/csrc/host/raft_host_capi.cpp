@@ -1,0 +1,161 @@
+// raft_host_capi.cpp -- flat C hooks over raft_host.hpp so that the Python
+// tests can drive the C++ host the way Go tests inside `package raft` would
+// drive the Go host.  Not part of the product ABI (that is include/rq.h).
+#include <cstring>
+#include <memory>
+
+#include "raft_host.hpp"
+
+using namespace raft;
+
+struct rh_cluster {
+    uint32_t G = 0, n = 0;
+    std::vector<Node *> nodes;  // group-major: nodes[g*n + p]
+    std::unique_ptr<BatchedDriver> driver;
+    RoundBuffers last;
+    ~rh_cluster() {
+        driver.reset();
+        for (Node *x : nodes) delete x;
+    }
+};
+
+extern "C" {
+
+// G groups of n members each, created with NewNode like a Go test would.
+rh_cluster *rh_cluster_new(uint32_t G, uint32_t n) {
+    auto *c = new rh_cluster();
+    c->G = G; c->n = n;
+    std::vector<Group> groups(G);
+    for (uint32_t g = 0; g < G; g++) {
+        std::vector<Node *> peers;
+        for (uint32_t p = 0; p < n; p++) {
+            Node *x = NewNode((int64_t)p, peers, nullptr);
+            peers.push_back(x);
+            c->nodes.push_back(x);
+        }
+        groups[g].Members = peers;
+    }
+    c->driver.reset(new BatchedDriver(std::move(groups), n));
+    return c;
+}
+
+void rh_cluster_free(rh_cluster *c) { delete c; }
+
+static Node *at(rh_cluster *c, uint32_t g, uint32_t p) { return c->nodes[(size_t)g * c->n + p]; }
+
+void rh_node_seed(rh_cluster *c, uint32_t g, uint32_t p, int64_t term, int64_t voted_for,
+                  int64_t node_type, int64_t commit_index) {
+    at(c, g, p)->SeedForTest(term, voted_for, (NodeType)node_type, commit_index);
+}
+
+void rh_node_seed_log(rh_cluster *c, uint32_t g, uint32_t p, const int64_t *terms, int64_t len) {
+    at(c, g, p)->SeedLogForTest(std::vector<int64_t>(terms, terms + len));
+}
+
+// out[9]: id, nodeType, currentTerm, votedFor, logLen, commitIndex, lastApplied, nPeers, hasLeaderArrays
+void rh_node_get(rh_cluster *c, uint32_t g, uint32_t p, int64_t *out) {
+    Node::State s = at(c, g, p)->Inspect();
+    const int64_t v[9] = {s.id, s.nodeType, s.currentTerm, s.votedFor, s.logLen, s.commitIndex,
+                          s.lastApplied, s.nPeers, s.hasLeaderArrays ? 1 : 0};
+    std::memcpy(out, v, sizeof v);
+}
+
+// next/match: n values each; returns 0 if the node holds no leader arrays.
+int rh_node_get_leader_arrays(rh_cluster *c, uint32_t g, uint32_t p, int64_t *next, int64_t *match) {
+    Node *x = at(c, g, p);
+    if (!x->Inspect().hasLeaderArrays) return 0;
+    for (uint32_t i = 0; i < c->n; i++) { next[i] = x->NextIndex()[i]; match[i] = x->MatchIndex()[i]; }
+    return 1;
+}
+
+// role: 0 = BecomeLeader, 1 = BecomeFollower, 2 = BecomeCandidate
+void rh_node_become(rh_cluster *c, uint32_t g, uint32_t p, int role) {
+    Node *x = at(c, g, p);
+    if (role == 0) x->BecomeLeader(); else if (role == 1) x->BecomeFollower(); else x->BecomeCandidate();
+}
+
+void rh_leader_set_match(rh_cluster *c, uint32_t g, uint32_t p, const int64_t *match) {
+    std::vector<int64_t> &m = at(c, g, p)->MatchIndexForTest();
+    for (uint32_t i = 0; i < c->n && i < m.size(); i++) m[i] = match[i];
+}
+
+// Group roles for the driver; slot -1 = none.
+void rh_group_roles(rh_cluster *c, uint32_t g, int leader_slot, int candidate_slot) {
+    Group &grp = c->driver->Groups()[g];
+    grp.Leader = leader_slot >= 0 ? at(c, g, (uint32_t)leader_slot) : nullptr;
+    grp.Candidate = candidate_slot >= 0 ? at(c, g, (uint32_t)candidate_slot) : nullptr;
+}
+
+// which slot leads / asks for votes after Apply (-1 = none)
+void rh_group_get_roles(rh_cluster *c, uint32_t g, int *leader_slot, int *candidate_slot) {
+    Group &grp = c->driver->Groups()[g];
+    *leader_slot = *candidate_slot = -1;
+    for (uint32_t p = 0; p < c->n; p++) {
+        if (grp.Members[p] == grp.Leader) *leader_slot = (int)p;
+        if (grp.Members[p] == grp.Candidate) *candidate_slot = (int)p;
+    }
+}
+
+// RPCs: return 0, or 1 where Go would panic (index out of range).
+int rh_request_vote(rh_cluster *c, uint32_t g, uint32_t p, int64_t term, int64_t cand, int64_t lli,
+                    int64_t llt, int64_t *term_result, int *granted) {
+    try {
+        auto r = at(c, g, p)->RequestVoteRPC(term, cand, lli, llt);
+        *term_result = r.first; *granted = r.second ? 1 : 0;
+        return 0;
+    } catch (const GoPanic &) { return 1; }
+}
+
+int rh_append_entries(rh_cluster *c, uint32_t g, uint32_t p, int64_t term, int64_t leader_id,
+                      int64_t prev_index, int64_t prev_term, const int64_t *new_index,
+                      const int64_t *new_term, int64_t n_new, int64_t leader_commit,
+                      int64_t *term_result, int *success) {
+    std::vector<Entry> ents;
+    for (int64_t i = 0; i < n_new; i++) ents.push_back(Entry{"x", new_index[i], new_term[i]});
+    try {
+        auto r = at(c, g, p)->AppendEntriesRPC(term, leader_id, prev_index, prev_term, ents, leader_commit);
+        *term_result = r.first; *success = r.second ? 1 : 0;
+        return 0;
+    } catch (const GoPanic &) { return 1; }
+}
+
+// Flatten into the cluster's buffer set; copies out what the caller asks for.
+// Planes are [n][G].  Returns the driver code (0, -1 shape, -2 range).
+int rh_driver_flatten(rh_cluster *c, int32_t *match, int32_t *commit, int32_t *leader_term,
+                      uint32_t *log_off, int32_t *log_term, uint64_t log_term_cap,
+                      int32_t *voter_term, int32_t *voted_for, int32_t *last_log_term,
+                      int32_t *cand_term, int32_t *cand_id, uint64_t *log_terms_used) {
+    RoundBuffers &b = c->last;
+    int rc = c->driver->Flatten(b);
+    if (rc != 0) return rc;
+    const size_t plane = (size_t)b.slots * b.groups * 4, vec = (size_t)b.groups * 4;
+    std::memcpy(match, b.match.data(), plane); std::memcpy(voter_term, b.voterTerm.data(), plane);
+    std::memcpy(voted_for, b.votedFor.data(), plane); std::memcpy(last_log_term, b.lastLogTerm.data(), plane);
+    std::memcpy(commit, b.commit.data(), vec); std::memcpy(leader_term, b.leaderTerm.data(), vec);
+    std::memcpy(cand_term, b.candTerm.data(), vec); std::memcpy(cand_id, b.candId.data(), vec);
+    std::memcpy(log_off, b.logOff.data(), ((size_t)b.groups + 1) * 4);
+    *log_terms_used = b.logTerm.size();
+    if (b.logTerm.size() > log_term_cap) return -3;
+    std::memcpy(log_term, b.logTerm.data(), b.logTerm.size() * 4);
+    return 0;
+}
+
+// Apply outputs (layout of rq_fused_round) to the objects; uses the shapes of the last Flatten.
+void rh_driver_apply(rh_cluster *c, const int32_t *commit_out, const int32_t *voter_term_out,
+                     const uint16_t *grant_mask, const uint16_t *stepdown_mask,
+                     const uint8_t *elected, const int32_t *max_term) {
+    RoundBuffers &b = c->last;
+    const size_t G = b.groups, plane = (size_t)b.slots * G;
+    b.commitOut.assign(commit_out, commit_out + G);
+    b.voterTermOut.assign(voter_term_out, voter_term_out + plane);
+    b.grantMask.assign(grant_mask, grant_mask + G);
+    b.stepdownMask.assign(stepdown_mask, stepdown_mask + G);
+    b.elected.assign(elected, elected + G);
+    b.maxTerm.assign(max_term, max_term + G);
+    c->driver->Apply(b);
+}
+
+// Flatten -> rq_fused_round on the GPU -> Apply.  Returns an RQ_* code.
+int rh_driver_step(rh_cluster *c, int device) { return c->driver->Step(device); }
+
+}  // extern "C"

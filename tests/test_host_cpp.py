@@ -1,0 +1,179 @@
+"""The C++ host (raft_amd/csrc/host): the reference's Go surface mirrored in
+compiled code (Go toolchain absent) and the BatchedDriver above the C-ABI.
+CPU tests cover the RPC methods against the hand-derived KATs and the
+flatten/apply logic against the oracle; the GPU test runs a whole Step()."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import host_lib as h
+import oracle_lib as o
+from raft_amd import synth
+
+KATS = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kats.json")))
+
+
+def test_new_node_and_roles():
+    c = h.Cluster(1, 3)
+    try:
+        for p in range(3):
+            s = c.get(0, p)
+            assert (s["id"], s["nodeType"], s["currentTerm"], s["votedFor"], s["logLen"], s["nPeers"]) == \
+                (p, h.FOLLOWER, 0, -1, 0, 3)                       # raft.go:80-97
+        c.seed(0, 1, 0, -1, h.FOLLOWER, log_terms=[0, 1, 1])
+        c.become(0, 1, 0)
+        nx, mt = c.leader_arrays(0, 1)
+        assert nx == [4, 4, 4] and mt == [0, 0, 0]                   # :108, :116
+        c.become(0, 1, 2)
+        assert c.get(0, 1)["nodeType"] == h.CANDIDATE and c.leader_arrays(0, 1) is None
+        assert c.get(0, 1)["currentTerm"] == 0                       # no term bump (:126-130)
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("k", KATS["vote"], ids=lambda k: k["id"])
+def test_request_vote_kats(k):
+    v, r, e = k["voter"], k["req"], k["expect"]
+    c = h.Cluster(1, 1)
+    try:
+        c.seed(0, 0, v["cur"], v["voted_for"], v["role"], log_terms=[v["last_log_term"]])
+        rc, tr, gr = c.request_vote(0, 0, r["term"], r["cand"], r["last_log_index"], r["last_log_term"])
+        s = c.get(0, 0)
+        assert (rc, tr, gr, s["currentTerm"], s["nodeType"], s["votedFor"]) == \
+            (0, e["term_result"], e["grant"], e["cur"], e["role"], v["voted_for"])
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("k", KATS["vote_empty_log"], ids=lambda k: k["id"])
+def test_request_vote_empty_log_panics_like_go(k):
+    c = h.Cluster(1, 1)
+    try:
+        c.seed(0, 0, k["voter"]["cur"], k["voter"]["voted_for"], k["voter"]["role"], log_terms=[])
+        rc, tr, gr = c.request_vote(0, 0, k["req"]["term"], k["req"]["cand"])
+        assert (rc == 1) == k["expect"]["panic"]
+        assert c.get(0, 0)["currentTerm"] == k["expect"]["cur"]
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("k", KATS["append"], ids=lambda k: k["id"])
+def test_append_entries_kats(k):
+    c = h.Cluster(1, 1)
+    try:
+        c.seed(0, 0, k["cur"], -1, h.FOLLOWER, log_terms=k["log_terms"])
+        rc, tr, ok = c.append_entries(0, 0, k["term"], 0, k["prev_index"], k["prev_term"], k["new"], k["leader_commit"])
+        e = k["expect"]
+        assert (rc == 1) == e["panic"]
+        s = c.get(0, 0)
+        if not e["panic"]:
+            assert (tr, ok) == (e["term_result"], e["success"])
+        for key, field in (("log_len", "logLen"), ("commit", "commitIndex"), ("cur", "currentTerm")):
+            if key in e:
+                assert s[field] == e[key]
+    finally:
+        c.close()
+
+
+def _build(G, n, seed):
+    """A cluster whose object state equals a synthetic batch; returns (cluster, batch)."""
+    b = synth.gen_fused(G, n, seed=seed)
+    c = h.Cluster(G, n)
+    for g in range(G):
+        lead = int(b.cand_id[g] + 1) % n                       # some member other than the candidate leads
+        lo, hi = int(b.log_off[g]), int(b.log_off[g + 1])
+        for p in range(n):
+            logs = [int(b.last_log_term[p, g])]
+            role = h.FOLLOWER
+            if p == lead:
+                logs = [int(x) for x in b.log_term[lo:hi]]
+            c.seed(g, p, int(b.voter_term[p, g]), int(b.voted_for[p, g]), role, 0, logs)
+        c.become(g, lead, 0)
+        c.seed(g, lead, int(b.leader_term[g]), int(b.voted_for[lead, g]), h.LEADER, int(b.commit[g]))
+        c.set_match(g, lead, [int(x) for x in b.match[:, g]])
+        cand = int(b.cand_id[g])
+        c.seed(g, cand, int(b.cand_term[g]), int(b.voted_for[cand, g]), h.CANDIDATE, 0)
+        c.roles(g, leader=lead, candidate=cand)
+        # the batch's voter planes must describe the objects: the leader's own slot carries its state
+        b.voter_term[lead, g] = b.leader_term[g]
+        b.last_log_term[lead, g] = b.log_term[hi - 1]
+        b.voter_term[cand, g] = b.cand_term[g]
+    return c, b
+
+
+def test_flatten_matches_the_objects_and_apply_matches_the_oracle():
+    G, n = 300, 5
+    c, b = _build(G, n, seed=17)
+    try:
+        rc, f = c.flatten()
+        assert rc == 0
+        for k in ("match", "commit", "leader_term", "log_off", "log_term", "voter_term", "voted_for",
+                  "last_log_term", "cand_term", "cand_id"):
+            assert np.array_equal(f[k], b[k]), k
+        r = o.fused_round(*b.fused_args())                  # oracle stands in for the GPU on CPU
+        c.apply(r)
+        for g in range(G):
+            lead, cand = int(b.cand_id[g] + 1) % n, int(b.cand_id[g])
+            for p in range(n):
+                s = c.get(g, p)
+                assert s["currentTerm"] == r.voter_term[p, g]
+                if (r.stepdown_mask[g] >> p) & 1:
+                    assert s["nodeType"] == h.FOLLOWER
+            assert c.get(g, lead)["commitIndex"] == r.commit[g]
+            new_lead, new_cand = c.get_roles(g)
+            if r.elected[g]:
+                assert new_lead == cand and new_cand == -1
+                assert c.get(g, cand)["nodeType"] == h.LEADER and c.leader_arrays(g, cand) is not None
+            else:
+                assert new_lead == lead and new_cand == cand
+    finally:
+        c.close()
+
+
+def test_flatten_rejects_values_outside_int32():
+    c = h.Cluster(1, 3)
+    try:
+        c.seed(0, 0, 1 << 40, -1, h.FOLLOWER, log_terms=[0])
+        rc, _ = c.flatten()
+        assert rc == -2
+    finally:
+        c.close()
+
+
+def test_groups_without_leader_or_candidate_are_inert():
+    G, n = 4, 3
+    c = h.Cluster(G, n)
+    try:
+        for g in range(G):
+            for p in range(n):
+                c.seed(g, p, 5 + p, -1, h.FOLLOWER, 0, [0, 1])
+        rc, f = c.flatten()
+        assert rc == 0
+        r = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                          f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
+        assert not r.elected.any() and not r.grant_mask.any() and not r.stepdown_mask.any()
+        assert np.array_equal(r.voter_term, f["voter_term"]) and np.array_equal(r.commit, f["commit"])
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_step_on_gpu_equals_per_node_reference_calls():
+    """BatchedDriver.Step() (one GPU launch) against the same round done one
+    RequestVoteRPC at a time on the oracle's reference-shaped nodes."""
+    G, n = 2000, 5
+    c, b = _build(G, n, seed=23)
+    try:
+        r = o.fused_round(*b.fused_args())
+        assert c.step(0) == 0
+        for g in range(G):
+            lead, cand = int(b.cand_id[g] + 1) % n, int(b.cand_id[g])
+            for p in range(n):
+                assert c.get(g, p)["currentTerm"] == r.voter_term[p, g]
+            assert c.get(g, lead)["commitIndex"] == r.commit[g]
+            assert (c.get_roles(g)[0] == cand) == bool(r.elected[g])
+        assert c.step(0) == 0                      # a second round on the applied state
+    finally:
+        c.close()
