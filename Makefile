@@ -12,8 +12,8 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h include/rq.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-raft_amd/librq.so: build/rq_kernels.o build/rq_engine.o
-	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -o $@
+raft_amd/librq.so: build/rq_kernels.o build/rq_engine.o build/rq_comm.o
+	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -ldl -o $@
 
 HOST = $(CSRC)/host
 raft_amd/libraft_host.so: $(HOST)/raft_host.cpp $(HOST)/raft_host_capi.cpp $(HOST)/raft_host.hpp include/rq.h raft_amd/librq.so

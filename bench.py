@@ -50,6 +50,14 @@ def parse():
                     help="plane stride = groups + pad (elements): keeps the slot planes off one power-of-two stride")
     ap.add_argument("--skew", type=int, default=-1, help="one slab per set, arrays skewed by this many bytes (-1: separate allocations)")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
+    ap.add_argument("--summary", choices=["u16", "i32"], default="u16",
+                    help="commit summary on the wire: 16-bit window with escape (default) or full int32")
+    ap.add_argument("--rounds-per-exchange", type=int, default=4,
+                    help="summaries of this many consecutive rounds travel in one all-gather")
+    ap.add_argument("--exchange-impl", choices=["auto", "native", "torch"], default="torch",
+                    help="summary all-gather through librq's own RCCL communicator or torch.distributed")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="initialise torch.distributed and run the summary all-gather even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
@@ -103,8 +111,10 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()    # one rank per GPU on a real node
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    use_dist = world > 1 or args.force_exchange
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
@@ -112,9 +122,16 @@ def main():
 
     G, n, S = args.groups, args.peers, max(1, args.sets)
     eng = DeviceEngine(dev_index)
-    exchange = world > 1 and not args.no_exchange
-    ex = SummaryExchange(G, device, depth=S) if exchange else None
+    exchange = use_dist and not args.no_exchange
+    R = max(1, min(args.rounds_per_exchange, S))
+    while S % R:
+        R -= 1                                   # every input set maps to one (slot, round-in-slot)
+    depth = S // R
+    ex = SummaryExchange(G, device, depth=depth, mode=args.summary, impl=args.exchange_impl,
+                         rounds=R) if exchange else None
 
+    # one run-long counter of groups whose commit offset left the 16-bit summary window
+    escape_counter = torch.zeros(2, dtype=torch.int32, device=device) if ex is not None else None
     sets, first_mixed = [], None
     for s in range(S):
         seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
@@ -126,8 +143,11 @@ def main():
         kw = {}
         if args.workload == "mixed" and sets:
             kw["share_log_with"] = sets[0]
-        if ex is not None:
-            kw.update(commit_out=ex.commit_view(s), elected_bits=ex.bits_view(s))
+        if ex is not None and args.summary == "i32":
+            kw.update(commit_out=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R))
+        elif ex is not None:
+            kw.update(commit_lo16=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R),
+                      summary_escapes=escape_counter)
         if args.skew >= 0:
             kw["skew_bytes"] = args.skew
         sets.append(DeviceBatch(b, device, **kw))
@@ -143,22 +163,22 @@ def main():
 
     def step(i):
         s = i % S
-        if ex is not None:
-            ex.wait(s)                       # slot s's previous all-gather must be done
+        if ex is not None and s % R == 0:
+            ex.begin(s // R)                 # the slot's previous all-gather must be done
         if args.what == "fused":
             eng.fused_round(sets[s], variant=args.variant, want_bits=not args.no_bits, status=not args.no_status)
         elif args.what == "commit":
             eng.commit_advance(sets[s], variant=args.variant)
         else:
             eng.vote_tally(sets[s], variant=args.variant)
-        if ex is not None:
-            ex.exchange(s, async_op=True)
+        if ex is not None and s % R == R - 1:
+            ex.exchange(s // R, async_op=True)   # R rounds of summaries in one collective
 
     def fence():
         if ex is not None:
             ex.wait_all()
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -176,17 +196,20 @@ def main():
         ex.wait_all()
     torch.cuda.synchronize(device)
     t1 = time.perf_counter()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
     wall = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # avg launch duration on the kernel's stream
 
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
 
+    summary_escapes = None
+    if ex is not None:      # the 16-bit window must have held on this rank for the whole run
+        summary_escapes = int(escape_counter[0].item())
     if rank == 0:
         total_groups = G * world
         value = total_groups * args.steps / wall
@@ -206,7 +229,12 @@ def main():
             "dtype": "int32", "data": "synthetic",
             "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
                        "resident_mb_per_gpu": round(resident_mb, 1),
-                       "summary_allgather": bool(exchange), "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "skew": args.skew,
+                       "summary_allgather": bool(exchange),
+                       "summary_bytes_per_rank": ex.nbytes if ex is not None else 0,
+                       "summary_mode": args.summary if ex is not None else None,
+                       "summary_impl": ex.impl if ex is not None else None,
+                       "rounds_per_allgather": R if ex is not None else None,
+                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "skew": args.skew,
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -218,7 +246,9 @@ def main():
         print(json.dumps(line), flush=True)
 
     eng.close()
-    if world > 1:
+    if ex is not None:
+        ex.close()
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -47,6 +47,7 @@ extern "C" {
 #define RQ_E_NODEVICE   -5  /* no such GPU / not a gfx950 device               */
 #define RQ_E_STATE      -6  /* rq_step/rq_download before rq_upload            */
 #define RQ_E_MASK       -7  /* joint: an empty configuration mask              */
+#define RQ_E_COMM       -8  /* RCCL unavailable or a collective call failed    */
 
 /* status_out bits (one byte per group) */
 #define RQ_ST_LOG_OOB   0x01u /* commit: N > commitIndex but N is outside the
@@ -224,7 +225,13 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  * The launch is enqueued and the call returns without synchronising.
  * elected_bits, if not NULL, receives the elected decisions packed 1 bit per
  * group ([ceil(G/64)] uint64, bit g%64 of word g/64): the summary vector
- * ranks exchange in a sharded deployment.  variant selects a kernel build:
+ * ranks exchange in a sharded deployment.  commit_lo16, if not NULL, receives
+ * the other half of that summary in 16 bits per group: commit'[g] -
+ * summary_base[g] (summary_base NULL = 0) when that lies in [0, 65535), else
+ * the escape value 65535, in which case *summary_escapes (if not NULL) is
+ * incremented and the receiver must fetch the full commit vector; the host
+ * moves summary_base forward before offsets reach the window's end.
+ * variant selects a kernel build:
  * 0 = library default; other values are tuning knobs listed in rq_kernels.h
  * and never change results. */
 int rq_fused_round_dev(rq_engine *e, void *stream, int variant,
@@ -238,7 +245,9 @@ int rq_fused_round_dev(rq_engine *e, void *stream, int variant,
                        int32_t *commit_out, int32_t *voter_term_out,
                        uint16_t *grant_mask, uint16_t *stepdown_mask,
                        uint8_t *elected, int32_t *max_term,
-                       uint8_t *status_out, uint64_t *elected_bits);
+                       uint8_t *status_out, uint64_t *elected_bits,
+                       uint16_t *commit_lo16, const int32_t *summary_base,
+                       uint32_t *summary_escapes);
 int rq_commit_advance_dev(rq_engine *e, void *stream, int variant,
                           uint32_t G, uint32_t n, uint32_t ld,
                           const int32_t *match, const int32_t *commit,
@@ -266,7 +275,9 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant,
                              int32_t *commit_out, int32_t *voter_term_out,
                              uint16_t *grant_mask, uint16_t *stepdown_mask,
                              uint8_t *elected, int32_t *max_term,
-                             uint8_t *status_out, uint64_t *elected_bits);
+                             uint8_t *status_out, uint64_t *elected_bits,
+                             uint16_t *commit_lo16, const int32_t *summary_base,
+                             uint32_t *summary_escapes);
 int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
                         const uint16_t *active_mask,
                         const int32_t *follower_term, const int32_t *leader_term,
@@ -277,6 +288,48 @@ int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint
                         uint16_t *stepdown_mask, int32_t *match_index_io,
                         int32_t *next_index_io, uint8_t *status_out);
 int rq_stream_sync(rq_engine *e, void *stream);
+
+/* Device memory for hosts that keep group state resident without another GPU
+ * runtime binding (a Go host has none), to be used with the *_dev launches.
+ * kind selects the hipExtMallocWithFlags flavour: 0 = ordinary device memory,
+ * 1 = fine-grained, 2 = uncached.  (On MI355X the flavour did not change how
+ * the log-term gather is fetched: every HBM read stayed a 128-byte request.)
+ * The copies are synchronous. */
+#define RQ_MEM_DEFAULT     0
+#define RQ_MEM_FINEGRAINED 1
+#define RQ_MEM_UNCACHED    2
+int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out);
+int rq_device_free(rq_engine *e, void *ptr);
+int rq_copy_to_device(rq_engine *e, void *dst, const void *src, uint64_t bytes);
+int rq_copy_from_device(rq_engine *e, void *dst, const void *src, uint64_t bytes);
+
+/* ---- sharded deployment: the per-round summary exchange ------------------ *
+ * Groups are independent, so ranks (one process per GPU) share nothing in the
+ * decision kernels; the only exchange step of a round is an all-gather of each
+ * rank's summary message (commit summary + elected bits, laid out by the
+ * host) over RCCL/xGMI.  No counterpart in the reference (its "RPC" is a
+ * method call on a pointer in the same address space, raft.go:26).
+ * rq_comm_unique_id: rank 0 creates the 128-byte id and hands it to the other
+ * ranks by any means (the Python host uses torch.distributed's store).
+ * rq_comm_allgather: posts an all-gather of `bytes` bytes per rank (send ->
+ * recv[rank*bytes ...]) ordered after everything already enqueued on
+ * compute_stream; a worker thread owned by the communicator enqueues it on the
+ * communicator's side stream, so the call returns in a few microseconds.
+ * rq_comm_wait: orders compute_stream after slot's last all-gather (call
+ * before a round overwrites that slot's buffers; required between two uses of
+ * one slot).  rq_comm_sync: host waits for every posted all-gather.  `slots`
+ * independent slots let the all-gather of round i overlap the kernels of
+ * rounds i+1..; a rq_comm is driven by one caller thread at a time. */
+typedef struct rq_comm rq_comm;
+int rq_comm_unique_id(uint8_t *out128);
+int rq_comm_create(int device, const uint8_t *id128, int rank, int world, uint32_t slots,
+                   rq_comm **out);
+int rq_comm_destroy(rq_comm *c);
+int rq_comm_allgather(rq_comm *c, void *compute_stream, uint32_t slot, const void *send,
+                      void *recv, uint64_t bytes);
+int rq_comm_wait(rq_comm *c, void *compute_stream, uint32_t slot);
+int rq_comm_sync(rq_comm *c);
+int rq_comm_last_error(const rq_comm *c, int *nccl_result, int *hip_error);
 
 #ifdef __cplusplus
 }

@@ -41,16 +41,27 @@ PROTOTYPES = {
     "rq_follower_clamp": [vp, u64, i32p, i32p, i32p, i32p],
     "rq_append_check": [vp, u32, u32, u32, u16p, i32p, i32p, i32p, i32p, i32p, u32p, i32p,
                         i32p, u16p, u16p, i32p, i32p, u8p],
-    "rq_append_check_dev": [vp, vp, u32, u32, u32] + [vp] * 15,
+    "rq_append_check_dev": [vp, vp, u32, u32, u32] + [vp] * 14,
     "rq_upload": [vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN,
     "rq_step": [vp, u32],
     "rq_download": [vp, i32p] + _VOTE_OUT + [u8p],
     # device-pointer launches: raw addresses (void*) so torch data_ptr() ints pass through
-    "rq_fused_round_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 18,
+    "rq_fused_round_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 21,
     "rq_commit_advance_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 7,
     "rq_vote_tally_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 12,
-    "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 20,
+    "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 23,
     "rq_stream_sync": [vp, vp],
+    "rq_comm_unique_id": [u8p],
+    "rq_comm_create": [cint, u8p, cint, cint, u32, C.POINTER(vp)],
+    "rq_comm_destroy": [vp],
+    "rq_comm_allgather": [vp, vp, u32, vp, vp, u64],
+    "rq_comm_wait": [vp, vp, u32],
+    "rq_comm_sync": [vp],
+    "rq_comm_last_error": [vp, C.POINTER(cint), C.POINTER(cint)],
+    "rq_device_alloc": [vp, u64, cint, C.POINTER(vp)],
+    "rq_device_free": [vp, vp],
+    "rq_copy_to_device": [vp, vp, vp, u64],
+    "rq_copy_from_device": [vp, vp, vp, u64],
 }
 
 _lib = None

@@ -210,6 +210,7 @@ const char *rq_strerror(int code) {
     case RQ_E_NODEVICE: return "no usable gfx950 device";
     case RQ_E_STATE: return "no resident round (call rq_upload first)";
     case RQ_E_MASK: return "empty joint-consensus configuration mask";
+    case RQ_E_COMM: return "RCCL unavailable or collective failed";
     default: return "unknown rq error";
     }
 }
@@ -602,7 +603,9 @@ int rq_fused_round_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint
                        const int32_t *voter_last_log_term, const int32_t *cand_term,
                        const int32_t *cand_id, int32_t *commit_out, int32_t *voter_term_out,
                        uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
-                       int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits) {
+                       int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
+                       uint16_t *commit_lo16, const int32_t *summary_base,
+                       uint32_t *summary_escapes) {
     rq_round_args a;
     std::memset(&a, 0, sizeof a);
     a.G = G; a.ld = ld; a.m = n;
@@ -613,6 +616,7 @@ int rq_fused_round_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint
     a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
     a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
     a.status_out = status_out; a.elected_bits = elected_bits;
+    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
     return dev_launch(e, stream, variant, n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
 }
 
@@ -655,7 +659,9 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G
                              const int32_t *cand_term, const int32_t *cand_id,
                              int32_t *commit_out, int32_t *voter_term_out, uint16_t *grant_mask,
                              uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
-                             uint8_t *status_out, uint64_t *elected_bits) {
+                             uint8_t *status_out, uint64_t *elected_bits,
+                             uint16_t *commit_lo16, const int32_t *summary_base,
+                             uint32_t *summary_escapes) {
     rq_round_args a;
     std::memset(&a, 0, sizeof a);
     a.G = G; a.ld = ld; a.m = m;
@@ -667,7 +673,42 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G
     a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
     a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
     a.status_out = status_out; a.elected_bits = elected_bits;
+    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
     return dev_launch(e, stream, variant, m, true, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
+}
+
+int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out) {
+    if (!e || !out || bytes == 0 || kind < 0 || kind > 2) return RQ_E_ARG;
+    *out = nullptr;
+    RQ_HIP(e, hipSetDevice(e->device));
+    const unsigned flags = kind == RQ_MEM_UNCACHED ? hipDeviceMallocUncached
+                         : kind == RQ_MEM_FINEGRAINED ? hipDeviceMallocFinegrained
+                                                      : hipDeviceMallocDefault;
+    hipError_t err = hipExtMallocWithFlags(out, (size_t)bytes, flags);
+    if (err != hipSuccess) { e->last_hip.store((int)err); *out = nullptr; return RQ_E_NOMEM; }
+    return RQ_OK;
+}
+
+int rq_device_free(rq_engine *e, void *ptr) {
+    if (!e) return RQ_E_ARG;
+    if (!ptr) return RQ_OK;
+    RQ_HIP(e, hipSetDevice(e->device));
+    RQ_HIP(e, hipFree(ptr));
+    return RQ_OK;
+}
+
+int rq_copy_to_device(rq_engine *e, void *dst, const void *src, uint64_t bytes) {
+    if (!e || (bytes && (!dst || !src))) return RQ_E_ARG;
+    RQ_HIP(e, hipSetDevice(e->device));
+    if (bytes) RQ_HIP(e, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return RQ_OK;
+}
+
+int rq_copy_from_device(rq_engine *e, void *dst, const void *src, uint64_t bytes) {
+    if (!e || (bytes && (!dst || !src))) return RQ_E_ARG;
+    RQ_HIP(e, hipSetDevice(e->device));
+    if (bytes) RQ_HIP(e, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return RQ_OK;
 }
 
 int rq_stream_sync(rq_engine *e, void *stream) {

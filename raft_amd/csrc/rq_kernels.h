@@ -35,6 +35,11 @@ struct rq_round_args {
     int32_t  *max_term;
     uint8_t  *status_out;    // may be null
     uint64_t *elected_bits;  // may be null
+    // narrow summary for the sharded exchange (all may be null):
+    // commit_lo16[g] = commit'[g] - summary_base[g] if that is in [0, 65535), else 65535
+    uint16_t *commit_lo16;
+    const int32_t *summary_base;   // null = 0
+    uint32_t *summary_escapes;     // incremented once per group that did not fit
 };
 
 // Kernel build selector ("variant" in the C-ABI).  Never changes results.

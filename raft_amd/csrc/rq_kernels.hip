@@ -229,6 +229,25 @@ __device__ __forceinline__ int32_t gather_term(const int32_t *p, uint32_t policy
     }
 }
 
+// 16-bit window of the commit summary: offset from a per-group base, 65535 =
+// "does not fit, fetch the full vector" (counted in summary_escapes).
+template <int V, bool NTS, bool FULL>
+__device__ __forceinline__ void store_commit_lo16(const rq_round_args &a, uint32_t g0, int valid,
+                                                  const int32_t (&co)[V]) {
+    uint32_t lo[V];
+    uint32_t escapes = 0;
+#pragma unroll
+    for (int k = 0; k < V; k++) {
+        const int32_t base = (a.summary_base && k < valid) ? a.summary_base[g0 + k] : 0;
+        const long long d = (long long)co[k] - (long long)base;
+        const bool fit = d >= 0 && d < 65535;
+        lo[k] = fit ? (uint32_t)d : 65535u;
+        escapes += (!fit && k < valid) ? 1u : 0u;
+    }
+    st_u16<V, NTS, FULL>(a.commit_lo16 + g0, valid, lo);
+    if (escapes && a.summary_escapes) atomicAdd(a.summary_escapes, escapes);
+}
+
 // ---------------------------------------------------------------------------
 // fixed cluster size n = N for every group
 // ---------------------------------------------------------------------------
@@ -333,6 +352,7 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
         }
         st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
+        if (a.commit_lo16) store_commit_lo16<V, NTS, FULL>(a, g0, valid, co);
     }
     if (a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
     return el_field;
@@ -585,7 +605,10 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
             co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
         }
-        if (in_range) st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
+        if (in_range) {
+            st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
+            if (a.commit_lo16) store_commit_lo16<V, NTS, FULL>(a, g0, valid, co);
+        }
     }
     if (in_range && a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
     return el_field;
@@ -609,8 +632,8 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args a) {
 }
 
 // ---------------------------------------------------------------------------
-// AppendEntries consistency batch: one thread per group, slots in chunks of 4
-// whose loads are all issued before the dependent log gathers.
+// AppendEntries consistency batch: one thread per group; all plane loads of
+// the group's slots are issued before the dependent log gathers.
 //   stepdown : term > cur, cur' = max(cur, term)                 (raft.go:142, :219-221)
 //   reach    : !(term < cur')                                    (:145-147)
 //   success  : reach && log[prevLogIndex].TermNum == prevLogTerm (:151-153)
@@ -621,66 +644,66 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args a) {
 // next = match + 1; rejected at the log check -> next = max(next - 1, 1);
 // rejected for a stale term -> unchanged.
 // ---------------------------------------------------------------------------
+// NMAX = compile-time slot bound (the loop over slots is fully unrolled so that
+// every plane load of a group is in flight before the first gather).
+template <int NMAX>
 __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args a) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.G) return;
-    constexpr int C = 4;
     const size_t ld = a.ld;
     const uint32_t n = a.n;
     const int32_t lt = __builtin_nontemporal_load(a.leader_term + g);
     uint32_t act = a.active_mask ? (uint32_t)a.active_mask[g] : 0xFFFFu;
     act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
-    uint32_t ok = 0, sd = 0, st = 0;
-    for (uint32_t c0 = 0; c0 < n; c0 += C) {
-        int32_t ft[C], pi[C], pt[C], nn[C], mi[C], ni[C], tg[C];
-        uint32_t o0[C], o1[C];
-        bool live[C];
+    const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
+    int32_t ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX];
+    uint32_t o0[NMAX], o1[NMAX];
 #pragma unroll
-        for (int q = 0; q < C; q++) {
-            const uint32_t p = c0 + q;
-            live[q] = p < n && ((act >> p) & 1u);
-            ft[q] = pi[q] = pt[q] = nn[q] = mi[q] = 0; ni[q] = 1; o0[q] = o1[q] = 0;
-            if (live[q]) {
-                const size_t s = p * ld + g;
-                ft[q] = __builtin_nontemporal_load(a.follower_term + s);
-                pi[q] = __builtin_nontemporal_load(a.prev_log_index + s);
-                pt[q] = __builtin_nontemporal_load(a.prev_log_term + s);
-                o0[q] = __builtin_nontemporal_load(a.flog_off + s);
-                o1[q] = a.flog_off[s + 1];
-                if (a.n_new) nn[q] = __builtin_nontemporal_load(a.n_new + s);
-                if (a.match_index_io) mi[q] = __builtin_nontemporal_load(a.match_index_io + s);
-                if (a.next_index_io) ni[q] = __builtin_nontemporal_load(a.next_index_io + s);
-            }
-        }
-        bool reach[C], inb[C];
-#pragma unroll
-        for (int q = 0; q < C; q++) {
-            reach[q] = live[q] && lt >= ft[q];
-            inb[q] = (uint32_t)pi[q] < (o1[q] - o0[q]);
-            tg[q] = 0;
-            if (reach[q] && inb[q]) tg[q] = a.flog_term[(size_t)o0[q] + (uint32_t)pi[q]];
-        }
-#pragma unroll
-        for (int q = 0; q < C; q++) {
-            if (!live[q]) continue;
-            const uint32_t p = c0 + q;
+    for (int p = 0; p < NMAX; p++) {
+        ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
+        if ((act >> p) & 1u) {
             const size_t s = p * ld + g;
-            const bool success = reach[q] && inb[q] && tg[q] == pt[q];
-            sd |= (uint32_t)(lt > ft[q]) << p;
-            ok |= (uint32_t)success << p;
-            st |= (reach[q] && !inb[q]) ? kStLogOob : 0;
-            __builtin_nontemporal_store(max(ft[q], lt), a.follower_term_out + s);
-            if (a.match_index_io || a.next_index_io) {
-                int32_t m2 = mi[q], n2 = ni[q];
-                if (success) { m2 = (int32_t)((uint32_t)pi[q] + (uint32_t)nn[q]); n2 = (int32_t)((uint32_t)m2 + 1u); }
-                else if (reach[q]) { n2 = n2 > 1 ? n2 - 1 : 1; }
-                if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
-                if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
-            }
+            ft[p] = __builtin_nontemporal_load(a.follower_term + s);
+            pi[p] = __builtin_nontemporal_load(a.prev_log_index + s);
+            pt[p] = __builtin_nontemporal_load(a.prev_log_term + s);
+            o0[p] = __builtin_nontemporal_load(a.flog_off + s);
+            o1[p] = a.flog_off[s + 1];
+            if (a.n_new) nn[p] = __builtin_nontemporal_load(a.n_new + s);
+            if (a.match_index_io) mi[p] = __builtin_nontemporal_load(a.match_index_io + s);
+            if (a.next_index_io) ni[p] = __builtin_nontemporal_load(a.next_index_io + s);
         }
     }
-    a.success_mask[g] = (uint16_t)ok;
-    a.stepdown_mask[g] = (uint16_t)sd;
+    uint32_t reach = 0, inb = 0;
+#pragma unroll
+    for (int p = 0; p < NMAX; p++) {
+        const bool r = ((act >> p) & 1u) && lt >= ft[p];
+        const bool in = (uint32_t)pi[p] < (o1[p] - o0[p]);
+        reach |= (uint32_t)r << p;
+        inb |= (uint32_t)in << p;
+        tg[p] = 0;
+        if (r && in) tg[p] = __builtin_nontemporal_load(a.flog_term + ((size_t)o0[p] + (uint32_t)pi[p]));
+    }
+    uint32_t ok = 0, sd = 0, st = 0;
+#pragma unroll
+    for (int p = 0; p < NMAX; p++) {
+        if (!((act >> p) & 1u)) continue;
+        const size_t s = p * ld + g;
+        const bool r = (reach >> p) & 1u, in = (inb >> p) & 1u;
+        const bool success = r && in && tg[p] == pt[p];
+        sd |= (uint32_t)(lt > ft[p]) << p;
+        ok |= (uint32_t)success << p;
+        st |= (r && !in) ? kStLogOob : 0;
+        __builtin_nontemporal_store(max(ft[p], lt), a.follower_term_out + s);
+        if (upd) {
+            int32_t m2 = mi[p], n2 = ni[p];
+            if (success) { m2 = (int32_t)((uint32_t)pi[p] + (uint32_t)nn[p]); n2 = (int32_t)((uint32_t)m2 + 1u); }
+            else if (r) { n2 = n2 > 1 ? n2 - 1 : 1; }
+            if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
+            if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
+        }
+    }
+    __builtin_nontemporal_store((uint16_t)ok, a.success_mask + g);
+    __builtin_nontemporal_store((uint16_t)sd, a.stepdown_mask + g);
     if (a.status_out) a.status_out[g] = (uint8_t)st;
 }
 
@@ -799,7 +822,7 @@ int pick_v(const rq_round_args &a, int want, int what) {
     for (int v = want; v > 1; v >>= 1) {
         bool ok = (a.ld % v) == 0;
         if (what & RQ_WHAT_COMMIT)
-            ok = ok && aligned_to(a.match, 4 * v) && aligned_to(a.commit, 4 * v) &&
+            ok = ok && aligned_to(a.commit_lo16, 2 * v) && aligned_to(a.match, 4 * v) && aligned_to(a.commit, 4 * v) &&
                  aligned_to(a.leader_term, 4 * v) && aligned_to(a.log_off, 4 * v) &&
                  aligned_to(a.commit_out, 4 * v);
         if (what & RQ_WHAT_VOTE)
@@ -862,8 +885,19 @@ hipError_t rq_launch_append_check(const rq_append_args &a, hipStream_t stream) {
     if (a.G == 0) return hipSuccess;
     if (a.G > 0x7FFFFFFFu || a.ld < a.G || a.n < 1 || a.n > 16) return hipErrorInvalidValue;
     const uint32_t block = 128;
-    const uint32_t grid = (a.G + block - 1) / block;
-    hipLaunchKernelGGL(rq_append_check_kernel, dim3(grid), dim3(block), 0, stream, a);
+    const dim3 grid((a.G + block - 1) / block), blk(block);
+    switch (a.n) {
+    case 1: hipLaunchKernelGGL(rq_append_check_kernel<1>, grid, blk, 0, stream, a); break;
+    case 2: hipLaunchKernelGGL(rq_append_check_kernel<2>, grid, blk, 0, stream, a); break;
+    case 3: hipLaunchKernelGGL(rq_append_check_kernel<3>, grid, blk, 0, stream, a); break;
+    case 4: hipLaunchKernelGGL(rq_append_check_kernel<4>, grid, blk, 0, stream, a); break;
+    case 5: hipLaunchKernelGGL(rq_append_check_kernel<5>, grid, blk, 0, stream, a); break;
+    case 6: hipLaunchKernelGGL(rq_append_check_kernel<6>, grid, blk, 0, stream, a); break;
+    case 7: hipLaunchKernelGGL(rq_append_check_kernel<7>, grid, blk, 0, stream, a); break;
+    case 8: hipLaunchKernelGGL(rq_append_check_kernel<8>, grid, blk, 0, stream, a); break;
+    case 9: hipLaunchKernelGGL(rq_append_check_kernel<9>, grid, blk, 0, stream, a); break;
+    default: hipLaunchKernelGGL(rq_append_check_kernel<16>, grid, blk, 0, stream, a); break;
+    }
     return hipGetLastError();
 }
 

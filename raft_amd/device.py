@@ -27,7 +27,8 @@ class DeviceBatch:
                "voter_term", "voted_for", "last_log_term", "cand_term", "cand_id")
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
-                 skew_bytes=None, share_log_with=None):
+                 skew_bytes=None, share_log_with=None, commit_lo16=None, summary_escapes=None,
+                 summary_base=None):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         skew_bytes: if not None, every array is carved from ONE device slab and
@@ -95,11 +96,19 @@ class DeviceBatch:
         if elected_bits is not None:
             assert elected_bits.numel() == (G + 63) // 64 and elected_bits.dtype == torch.int64
             o["elected_bits"] = elected_bits
+        # narrow (16-bit window) commit summary: only written when a buffer is supplied
+        if commit_lo16 is not None:
+            assert commit_lo16.numel() == G and commit_lo16.dtype == torch.int16
+            assert summary_escapes is not None and summary_escapes.dtype == torch.int32
+        o["commit_lo16"] = commit_lo16
+        o["summary_escapes"] = summary_escapes
+        self.summary_base = summary_base
         self.o = o
         self._args = {}
 
     def bytes_resident(self):
-        return sum(x.numel() * x.element_size() for x in list(self.t.values()) + list(self.o.values()))
+        return sum(x.numel() * x.element_size() for x in list(self.t.values()) + list(self.o.values())
+                   if x is not None)
 
     def results(self):
         """Outputs as numpy arrays with the C-ABI dtypes."""
@@ -114,6 +123,8 @@ class DeviceBatch:
             max_term=o["max_term"].cpu().numpy(),
             status=o["status"].cpu().numpy(),
             elected_bits=o["elected_bits"].cpu().numpy().view(np.uint64),
+            commit_lo16=None if o["commit_lo16"] is None else o["commit_lo16"].cpu().numpy().view(np.uint16),
+            summary_escapes=None if o["summary_escapes"] is None else int(o["summary_escapes"].cpu()[0]),
         )
 
 
@@ -142,6 +153,25 @@ class DeviceEngine:
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
+    def alloc(self, nbytes, kind=0):
+        """Raw device memory through the C-ABI (kind: 0 default, 1 fine-grained, 2 uncached)."""
+        import ctypes as C
+        p = C.c_void_p()
+        self._check(self._l.rq_device_alloc(self._h, nbytes, kind, C.byref(p)), "rq_device_alloc")
+        return p.value
+
+    def free(self, addr):
+        self._check(self._l.rq_device_free(self._h, addr), "rq_device_free")
+
+    def upload(self, addr, array):
+        a = np.ascontiguousarray(array)
+        self._check(self._l.rq_copy_to_device(self._h, addr, a.ctypes.data, a.nbytes), "rq_copy_to_device")
+
+    def download(self, addr, array):
+        """Fill the (contiguous) numpy array from device memory at addr."""
+        self._check(self._l.rq_copy_from_device(self._h, array.ctypes.data, addr, array.nbytes),
+                    "rq_copy_from_device")
+
     def fused_round(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
         """Enqueue one fused round for DeviceBatch b on torch's current stream."""
         key = (want_bits, status)
@@ -153,7 +183,10 @@ class DeviceEngine:
                     p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
                     p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
                     p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
-                    p(o["elected_bits"]) if want_bits else None]
+                    p(o["elected_bits"]) if want_bits else None,
+                    p(o["commit_lo16"]) if o["commit_lo16"] is not None else None,
+                    p(b.summary_base) if b.summary_base is not None else None,
+                    p(o["summary_escapes"]) if o["summary_escapes"] is not None else None]
             if b.joint:
                 tail = [p(t["old_mask"]), p(t["new_mask"])] + tail
             b._args[key] = tail

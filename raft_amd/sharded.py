@@ -1,16 +1,25 @@
 """Group-sharded deployment: one process per GPU, groups block-partitioned
 over ranks, and ONE exchange step per round -- an all-gather of the per-round
-summary (commitIndex' per group + the elected decisions packed 1 bit per
-group) over torch.distributed (backend "nccl" is RCCL over xGMI on MI355X;
+summary over torch.distributed (backend "nccl" is RCCL over xGMI on MI355X;
 "gloo" runs the same code on CPU tensors for tests).
 
 Raft groups are independent (no rule in raft.go:181-223 or in the commit rule
 reads another group's state), so the decision kernels need no collective; the
 summary exchange exists so that every rank can route client traffic and
 heartbeats for all groups.
+
+Summary per group: the elected decision (1 bit) and the new commitIndex.  xGMI
+is point-to-point (one ~77 GB/s link per peer and direction), and a round of
+1M groups takes ~30 us, so the exchange is sized for the link: by default the
+commitIndex travels as a 16-bit offset from a per-group base (2.1 bytes per
+group with the bit); an offset outside the window is sent as the escape value
+65535, which tells every receiver to fetch the full 32-bit vector of that
+round.  mode="i32" sends the 32-bit vector every round.
 """
 import torch
 import torch.distributed as dist
+
+ESCAPE = 65535
 
 
 def shard_bounds(total_groups, world_size, rank):
@@ -20,50 +29,153 @@ def shard_bounds(total_groups, world_size, rank):
     return g0, g1
 
 
-def summary_words(groups):
-    """int32 words of one rank's summary: G commit values + ceil(G/64) uint64 bit words."""
-    g_even = groups + (groups & 1)               # keeps the bit words 8-byte aligned
-    return g_even + 2 * ((groups + 63) // 64)
+def _up8(x):
+    return (x + 7) // 8 * 8
+
+
+def summary_bytes(groups, mode="u16"):
+    """Bytes of one rank's summary message: commit section (padded to 8), elected bit words."""
+    commit = groups * (2 if mode == "u16" else 4)
+    return _up8(commit) + 8 * ((groups + 63) // 64)
 
 
 class SummaryExchange:
     """`depth` independent summary slots so that the all-gather of round i can
     run on the communication stream while round i+1 computes into another slot.
-
     Every rank must use the same `groups` (pad the last shard if needed)."""
 
-    def __init__(self, groups, device, depth=2, group=None):
-        self.groups = int(groups)
+    def __init__(self, groups, device, depth=2, group=None, mode="u16", impl="auto", rounds=1):
+        """rounds: summaries of this many consecutive rounds share one message (one
+        collective per `rounds` rounds: enqueuing an RCCL collective costs tens of
+        microseconds of host time, more than a 1M-group round takes on the GPU).
+        impl: "native" = librq's own RCCL communicator and side stream (one C
+        call per exchange, a few microseconds of host time), "torch" =
+        torch.distributed collectives, "auto" = native on a GPU when every rank
+        can create the communicator, else torch."""
+        assert mode in ("u16", "i32") and impl in ("auto", "native", "torch")
+        self.groups, self.mode = int(groups), mode
         self.device = torch.device(device)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.words = summary_words(self.groups)
-        self.local = [torch.zeros(self.words, dtype=torch.int32, device=self.device) for _ in range(depth)]
-        self.all = [torch.zeros((self.world, self.words), dtype=torch.int32, device=self.device)
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rounds = int(rounds)
+        self.round_bytes = summary_bytes(self.groups, mode)
+        self.nbytes = self.rounds * self.round_bytes      # one rank's message
+        self._commit_bytes = self.groups * (2 if mode == "u16" else 4)
+        self._bits_off = _up8(self._commit_bytes)
+        self.local = [torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(depth)]
+        self.all = [torch.zeros((self.world, self.nbytes), dtype=torch.uint8, device=self.device)
                     for _ in range(depth)]
         self.work = [None] * depth
+        # On a GPU the collective is issued from a side stream and fenced with one
+        # event per slot: torch's async_op=True path costs ~30 us of host time per
+        # call on this stack, a blocking call on a side stream ~12 us, and the round
+        # itself is only ~30 us.
+        self._cuda = self.device.type == "cuda"
+        self._comm = None
+        if self._cuda and impl != "torch" and dist.is_initialized():
+            self._comm = self._native_comm(depth)
+            if self._comm is None and impl == "native":
+                raise RuntimeError("native RCCL communicator could not be created on every rank")
+        self.impl = "native" if self._comm is not None else "torch"
+        if self._cuda and self._comm is None:
+            self._side = torch.cuda.Stream(device=self.device)
+            self._done = [torch.cuda.Event() for _ in range(depth)]
+            self._pending = [False] * depth
+        dt = torch.int16 if mode == "u16" else torch.int32
+        rb = self.round_bytes
+        self._commit_views = [[t[r * rb: r * rb + self._commit_bytes].view(dt) for r in range(self.rounds)]
+                              for t in self.local]
+        self._bits_views = [[t[r * rb + self._bits_off: (r + 1) * rb].view(torch.int64) for r in range(self.rounds)]
+                            for t in self.local]
+        self._full = None          # lazily allocated [world, groups] int32 for the escape path
 
-    # views handed to the kernel as its commit_out / elected_bits outputs
-    def commit_view(self, slot):
-        return self.local[slot][: self.groups]
+    def _native_comm(self, depth):
+        """rq_comm_create on every rank with rank 0's unique id; None unless all ranks succeed."""
+        import ctypes as C
+        from . import _lib
+        l = _lib.lib()
+        idbuf = (C.c_uint8 * 128)()
+        ok = 1
+        if self.rank == 0 and l.rq_comm_unique_id(idbuf) != 0:
+            ok = 0
+        # the id travels as a tensor on the existing process group (works for nccl and gloo)
+        t = torch.tensor(list(idbuf) + [ok], dtype=torch.int32, device=self.device)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+        vals = t.cpu().tolist()
+        handle = C.c_void_p()
+        if vals[128]:
+            idbuf = (C.c_uint8 * 128)(*vals[:128])
+            rc = l.rq_comm_create(self.device.index or 0, idbuf, self.rank, self.world, depth, C.byref(handle))
+            ok = 1 if rc == 0 else 0
+        else:
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        if int(flag.item()) == 1:
+            self._l = l
+            self._send = [t_.data_ptr() for t_ in self.local]
+            self._recv = [t_.data_ptr() for t_ in self.all]
+            return handle
+        if handle.value:
+            l.rq_comm_destroy(handle)
+        return None
 
-    def bits_view(self, slot):
-        g_even = self.groups + (self.groups & 1)
-        return self.local[slot][g_even:].view(torch.int64)
+    def close(self):
+        if self._comm is not None:
+            self._l.rq_comm_destroy(self._comm)
+            self._comm = None
 
+    # ---- views handed to the kernel as outputs --------------------------------
+    def commit_view(self, slot, sub=0):
+        """Round `sub` of the slot: int32 [groups] (mode i32) or int16 [groups]
+        holding uint16 offsets (mode u16)."""
+        return self._commit_views[slot][sub]
+
+    def bits_view(self, slot, sub=0):
+        return self._bits_views[slot][sub]
+
+    def begin(self, slot):
+        """Call before the round that fills `slot`: waits for the slot's previous exchange."""
+        self.wait(slot)
+
+    # ---- the collective ------------------------------------------------------------
     def exchange(self, slot, async_op=True):
-        """All-gather slot's summary.  The collective is ordered after the work
-        already enqueued on the current stream (the round that produced it)."""
-        if self.world == 1:
+        """All-gather slot's summary, ordered after the work already enqueued on
+        the current stream (the round that produced it), without blocking that
+        stream: later rounds overlap with the collective."""
+        if self.world == 1 and not dist.is_initialized():
             self.all[slot][0].copy_(self.local[slot], non_blocking=True)
-            return None
+            return
+        if self._comm is not None:
+            rc = self._l.rq_comm_allgather(self._comm, torch.cuda.current_stream(self.device).cuda_stream,
+                                           slot, self._send[slot], self._recv[slot], self.nbytes)
+            if rc != 0:
+                raise RuntimeError("rq_comm_allgather failed: %d" % rc)
+            return
+        if self._cuda:
+            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(self._side):
+                dist.all_gather_into_tensor(self.all[slot].view(-1), self.local[slot], group=self.group)
+                self._done[slot].record(self._side)
+            self._pending[slot] = True
+            return
         w = dist.all_gather_into_tensor(self.all[slot].view(-1), self.local[slot],
                                         group=self.group, async_op=async_op)
         self.work[slot] = w if async_op else None
-        return w
 
     def wait(self, slot):
-        """Make the current stream (and, for gloo, the host) wait for slot's exchange."""
+        """Order the current stream (for gloo: the host) after slot's exchange."""
+        if self._comm is not None:
+            rc = self._l.rq_comm_wait(self._comm, torch.cuda.current_stream(self.device).cuda_stream, slot)
+            if rc != 0:
+                raise RuntimeError("rq_comm_wait failed: %d" % rc)
+            return
+        if self._cuda:
+            if self._pending[slot]:
+                torch.cuda.current_stream(self.device).wait_event(self._done[slot])
+                self._pending[slot] = False
+            return
         w = self.work[slot]
         if w is not None:
             w.wait()
@@ -72,9 +184,47 @@ class SummaryExchange:
     def wait_all(self):
         for s in range(len(self.work)):
             self.wait(s)
+        if self._comm is not None:          # host-level: the gathered buffers are about to be read
+            rc = self._l.rq_comm_sync(self._comm)
+            if rc != 0:
+                raise RuntimeError("rq_comm_sync failed: %d" % rc)
 
-    def gathered(self, slot):
-        """(commit [world, groups] int32, elected_bits [world, ceil(groups/64)] int64)."""
-        g_even = self.groups + (self.groups & 1)
-        a = self.all[slot]
-        return a[:, : self.groups], a[:, g_even:].contiguous().view(torch.int64)
+    # ---- reading a gathered slot --------------------------------------------------
+    def _section(self, slot, sub, lo, hi):
+        rb = self.round_bytes
+        return self.all[slot][:, sub * rb + lo: sub * rb + hi].contiguous()
+
+    def gathered_bits(self, slot, sub=0):
+        """elected bits of every rank: int64 [world, ceil(groups/64)]."""
+        return self._section(slot, sub, self._bits_off, self.round_bytes).view(torch.int64)
+
+    def gathered_escapes(self, slot, sub=0):
+        """Groups per rank whose offset left the 16-bit window: int64 [world]
+        (a reduction over the gathered message; synchronises if on a GPU)."""
+        if self.mode == "i32":
+            return torch.zeros(self.world, dtype=torch.int64)
+        lo = self._section(slot, sub, 0, self._commit_bytes).view(torch.int16)
+        return (lo.reshape(self.world, self.groups) == -1).sum(dim=1).cpu()      # 0xFFFF
+
+    def gathered_commit(self, slot, sub=0, base=None, full_local_commit=None):
+        """commitIndex of every group of every rank: int32 [world, groups].
+
+        mode u16: offsets are added to `base` ([world, groups] int32 or None = 0).
+        If any rank sent the escape value, `full_local_commit` (this rank's int32
+        commit' vector of that round) is all-gathered and used instead; every
+        rank sees the same message, so every rank takes this path together."""
+        if self.mode == "i32":
+            return self._section(slot, sub, 0, self._commit_bytes).view(torch.int32).reshape(self.world, self.groups)
+        if int(self.gathered_escapes(slot, sub).sum()) > 0:
+            if full_local_commit is None:
+                raise RuntimeError("a rank's commit offsets left the 16-bit window: pass full_local_commit")
+            if self._full is None:
+                self._full = torch.zeros((self.world, self.groups), dtype=torch.int32, device=self.device)
+            if dist.is_initialized():
+                dist.all_gather_into_tensor(self._full.view(-1), full_local_commit.contiguous(), group=self.group)
+            else:
+                self._full[0].copy_(full_local_commit)
+            return self._full
+        lo = self._section(slot, sub, 0, self._commit_bytes).view(torch.int16).reshape(self.world, self.groups)
+        out = lo.to(torch.int32) & 0xFFFF
+        return out if base is None else out + base

@@ -15,7 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as o  # noqa: E402
 from raft_amd import synth  # noqa: E402
-from raft_amd.sharded import SummaryExchange, shard_bounds, summary_words  # noqa: E402
+from raft_amd.sharded import ESCAPE, SummaryExchange, shard_bounds, summary_bytes  # noqa: E402
 
 
 def shard(b, g0, g1):
@@ -31,20 +31,24 @@ def shard(b, g0, g1):
     return s
 
 
-def main():
-    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+def run_mode(mode, rank, world, shift=0):
+    """shift > 0 moves rank 1's commit values past the 16-bit window in one round,
+    which must raise escapes and take the full-vector path."""
     per, rounds = 1000 + 37, 5                 # odd size: exercises the alignment padding
     total = per * world
-    ex = SummaryExchange(per, "cpu", depth=2)
-    assert ex.words == summary_words(per) and ex.world == world
-    expect = []
+    ex = SummaryExchange(per, "cpu", depth=2, mode=mode)
+    assert ex.nbytes == summary_bytes(per, mode) and ex.world == world
+    expect, mine_full = [], []
     for r in range(rounds):
         slot = r % 2
-        ex.wait(slot)                          # previous exchange of this slot
+        ex.begin(slot)                         # waits for the previous exchange of this slot
         if r >= 2:                             # ... whose result is checked before the slot is reused
-            check(ex, slot, expect[r - 2], per, world)
+            check(ex, slot, expect[r - 2], mine_full[r - 2], per, world)
         b = synth.gen_fused(total, 5, seed=900 + r)
+        if shift and r == 3:                   # only rank 1's shard leaves the window
+            b["commit"][per:2 * per] += shift
+            b["match"][:, per:2 * per] += shift
+            b["log_off"] = b["log_off"]        # N is now outside the log: commit stays, but is > 65535
         whole = o.fused_round(*b.fused_args())
         expect.append(whole)
         g0, g1 = shard_bounds(total, world, rank)
@@ -52,24 +56,75 @@ def main():
         mine = o.fused_round(*shard(b, g0, g1).fused_args())
         assert np.array_equal(mine.commit, whole.commit[g0:g1])     # sharding changes no decision
         assert np.array_equal(mine.elected, whole.elected[g0:g1])
-        ex.commit_view(slot).copy_(torch.from_numpy(mine.commit))
+        mine_full.append(torch.from_numpy(mine.commit.copy()))
+        if mode == "i32":
+            ex.commit_view(slot).copy_(torch.from_numpy(mine.commit))
+        else:                                  # what the kernel writes: 16-bit offsets, 65535 = escape
+            fit = (mine.commit >= 0) & (mine.commit < ESCAPE)
+            lo = np.where(fit, mine.commit, ESCAPE).astype(np.uint16)
+            ex.commit_view(slot).copy_(torch.from_numpy(lo.view(np.int16)))
         bits = np.packbits(mine.elected, bitorder="little")
         bits = np.concatenate([bits, np.zeros((-bits.size) % 8, np.uint8)]).view(np.int64)
         ex.bits_view(slot).copy_(torch.from_numpy(bits))
         ex.exchange(slot, async_op=True)
     ex.wait_all()
     for r in (rounds - 2, rounds - 1):
-        check(ex, r % 2, expect[r], per, world)
+        check(ex, r % 2, expect[r], mine_full[r], per, world)
     dist.barrier()
+
+
+def run_batched(rank, world, R=3):
+    """R consecutive rounds share one all-gather (SummaryExchange(rounds=R))."""
+    per, total = 517, 517 * world
+    ex = SummaryExchange(per, "cpu", depth=2, mode="u16", rounds=R)
+    assert ex.nbytes == R * summary_bytes(per, "u16")
+    for batch in range(3):
+        slot = batch % 2
+        ex.begin(slot)
+        wholes = []
+        for sub in range(R):
+            b = synth.gen_fused(total, 3, seed=40 + batch * R + sub)
+            whole = o.fused_round(*b.fused_args())
+            wholes.append(whole)
+            g0, g1 = shard_bounds(total, world, rank)
+            mine = o.fused_round(*shard(b, g0, g1).fused_args())
+            ex.commit_view(slot, sub).copy_(torch.from_numpy(mine.commit.astype(np.uint16).view(np.int16)))
+            bits = np.packbits(mine.elected, bitorder="little")
+            bits = np.concatenate([bits, np.zeros((-bits.size) % 8, np.uint8)]).view(np.int64)
+            ex.bits_view(slot, sub).copy_(torch.from_numpy(bits))
+        ex.exchange(slot)
+        ex.wait(slot)
+        for sub in range(R):
+            assert np.array_equal(ex.gathered_commit(slot, sub).numpy().reshape(-1), wholes[sub].commit)
+            bits = ex.gathered_bits(slot, sub)
+            for r in range(world):
+                got = np.unpackbits(bits[r].numpy().view(np.uint8), bitorder="little")[:per]
+                assert np.array_equal(got, wholes[sub].elected[r * per:(r + 1) * per])
+    dist.barrier()
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    run_batched(rank, world)
+    run_mode("i32", rank, world)
+    run_mode("u16", rank, world)
+    run_mode("u16", rank, world, shift=70000)
     if rank == 0:
         print("GLOO_SHARDED_OK")
     dist.destroy_process_group()
 
 
-def check(ex, slot, whole, per, world):
-    commit, bits = ex.gathered(slot)
+def check(ex, slot, whole, mine_full, per, world):
+    esc = ex.gathered_escapes(slot)
+    expect_esc = [int(((whole.commit[r * per:(r + 1) * per] < 0) |
+                       (whole.commit[r * per:(r + 1) * per] >= ESCAPE)).sum()) for r in range(world)]
+    if ex.mode == "u16":
+        assert esc.tolist() == expect_esc
+    commit = ex.gathered_commit(slot, 0, full_local_commit=mine_full)
     assert commit.shape == (world, per)
     assert np.array_equal(commit.numpy().reshape(-1), whole.commit)
+    bits = ex.gathered_bits(slot)
     for r in range(world):
         got = np.unpackbits(bits[r].numpy().view(np.uint8), bitorder="little")[:per]
         assert np.array_equal(got, whole.elected[r * per:(r + 1) * per])

@@ -36,7 +36,7 @@ def test_version_and_strerror():
     l = _lib.lib()
     assert l.rq_version() == 0x000100
     assert l.rq_strerror(0) == b"ok"
-    for code in range(-7, 0):
+    for code in range(-8, 0):
         assert l.rq_strerror(code) not in (b"", b"unknown rq error")
     assert l.rq_strerror(-99) == b"unknown rq error"
 

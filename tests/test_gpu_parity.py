@@ -363,3 +363,87 @@ def test_replicate_then_commit_closes_the_loop(engine):
     gc, gst = engine.commit_advance(got["match_index"], c.commit, c.leader_term, c.log_off, c.log_term)
     ec, est = o.commit_advance(exp["match_index"], c.commit, c.leader_term, c.log_off, c.log_term)
     assert np.array_equal(gc, ec) and np.array_equal(gst, est)
+
+
+def test_device_memory_helpers_round_trip(dev):
+    """rq_device_alloc / rq_copy_to_device / rq_copy_from_device / rq_device_free,
+    and a commit round on memory obtained through them (no torch allocations)."""
+    b = synth.gen_fused(4096, 3, seed=12)
+    exp_c, exp_st = o.commit_advance(*b.commit_args())
+    arrs = [b.match, b.commit, b.leader_term, b.log_off, b.log_term, np.zeros(b.G, np.int32), np.zeros(b.G, np.uint8)]
+    addrs = []
+    for kind, a in zip((0, 0, 1, 0, 2, 0, 0), arrs):
+        addr = dev.alloc(max(a.nbytes, 4), kind)
+        dev.upload(addr, a)
+        addrs.append(addr)
+    back = np.zeros_like(b.match)
+    dev.download(addrs[0], back)
+    assert np.array_equal(back, b.match)
+    rc = dev._l.rq_commit_advance_dev(dev._h, None, 0, b.G, b.n, b.ld, *addrs)
+    assert rc == 0
+    assert dev._l.rq_stream_sync(dev._h, None) == 0
+    c = np.zeros(b.G, np.int32); st = np.zeros(b.G, np.uint8)
+    dev.download(addrs[5], c); dev.download(addrs[6], st)
+    assert np.array_equal(c, exp_c) and np.array_equal(st, exp_st)
+    for addr in addrs:
+        dev.free(addr)
+
+
+@pytest.mark.parametrize("variant", [0, 0x234, 0x132])
+def test_narrow_commit_summary(dev, variant):
+    """commit_lo16 = commit' - base inside the 16-bit window, 65535 + an escape
+    count outside it; fixed and joint kernels."""
+    import torch
+    from raft_amd.device import DeviceBatch
+    rng = np.random.default_rng(5)
+    for joint in (False, True):
+        G = 70000 if variant != 0x234 else 70016
+        b = synth.gen_mixed(G, seed=3) if joint else synth.gen_fused(G, 5, seed=3, ld=G)
+        # push some groups out of the window on both sides
+        far = rng.random(G) < 0.01
+        b["commit"] = np.where(far, b.commit + 100000, b.commit).astype(np.int32)
+        base = rng.integers(0, 3, G).astype(np.int32)
+        base[rng.random(G) < 0.01] = 7                 # base above commit' -> negative offset
+        kw = dict(old_mask=b.old_mask, new_mask=b.new_mask) if joint else {}
+        exp = o.fused_round(*b.fused_args(), **kw)
+        lo16 = torch.zeros(G, dtype=torch.int16, device="cuda:0")
+        esc = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+        db = DeviceBatch(b, commit_lo16=lo16, summary_escapes=esc,
+                         summary_base=torch.from_numpy(base).to("cuda:0"))
+        dev.fused_round(db, variant=variant)
+        res = db.results()
+        assert np.array_equal(res["commit"], exp["commit"])
+        d = exp["commit"].astype(np.int64) - base
+        fit = (d >= 0) & (d < 65535)
+        assert np.array_equal(res["commit_lo16"], np.where(fit, d, 65535).astype(np.uint16))
+        assert res["summary_escapes"] == int((~fit).sum()) and res["summary_escapes"] > 0
+
+
+def test_native_rccl_summary_allgather_one_rank(dev):
+    """rq_comm_* (librq's own RCCL communicator, worker thread, side stream) with a
+    one-rank communicator: the gathered buffer equals the sent one, slot fencing
+    works, and a second use of a slot without rq_comm_wait is refused."""
+    import ctypes as C
+    import torch
+    l = dev._l
+    idbuf = (C.c_uint8 * 128)()
+    assert l.rq_comm_unique_id(idbuf) == 0
+    h = C.c_void_p()
+    assert l.rq_comm_create(0, idbuf, 0, 1, 3, C.byref(h)) == 0
+    try:
+        stream = torch.cuda.current_stream().cuda_stream
+        n = 1 << 20
+        send = [torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        recv = [torch.zeros(n, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        for it in range(4):
+            for s in range(3):
+                assert l.rq_comm_wait(h, stream, s) == 0
+                send[s].add_(1)                              # produced on the compute stream
+                assert l.rq_comm_allgather(h, stream, s, send[s].data_ptr(), recv[s].data_ptr(), n) == 0
+        assert l.rq_comm_allgather(h, stream, 0, send[0].data_ptr(), recv[0].data_ptr(), n) == -6
+        assert l.rq_comm_sync(h) == 0
+        torch.cuda.synchronize()
+        for s in range(3):
+            assert torch.equal(send[s], recv[s])
+    finally:
+        assert l.rq_comm_destroy(h) == 0

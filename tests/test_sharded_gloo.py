@@ -4,7 +4,7 @@ import socket
 import subprocess
 import sys
 
-from raft_amd.sharded import shard_bounds, summary_words
+from raft_amd.sharded import shard_bounds, summary_bytes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -19,11 +19,12 @@ def test_shard_bounds_cover_everything_once():
             assert max(sizes) - min(sizes) <= 1
 
 
-def test_summary_words_keep_bit_words_aligned():
-    for g in (1, 2, 63, 64, 65, 1037, 1 << 20):
-        w = summary_words(g)
-        g_even = g + (g & 1)
-        assert g_even % 2 == 0 and w == g_even + 2 * ((g + 63) // 64)
+def test_summary_layout_keeps_sections_aligned():
+    for mode, width in (("u16", 2), ("i32", 4)):
+        for g in (1, 2, 3, 63, 64, 65, 1037, 1 << 20):
+            n = summary_bytes(g, mode)
+            commit = (g * width + 7) // 8 * 8
+            assert n == commit + 8 * ((g + 63) // 64) and n % 8 == 0
 
 
 def test_two_ranks_gloo():

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""Times every BASELINE configuration that fits one GPU, plus the split
+kernels and the host-buffer (PCIe-inclusive) entry point, and writes one JSON
+document.  Run on the MI355X box:  python tools/config_report.py [out.json]
+
+All device timings are HIP-event time over back-to-back launches on the
+stream the kernels run on, divided by the launch count; input/output sets
+rotate so that neither reads nor writes stay in the 256 MB Infinity Cache.
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+from raft_amd import QuorumEngine, synth
+from raft_amd.device import DeviceBatch, DeviceEngine
+
+PEAK = 8.0e12
+dev = torch.device("cuda:0")
+eng = DeviceEngine(0)
+
+
+def timed(fn, steps, warmup=10):
+    for i in range(warmup):
+        fn(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        fn(i)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / steps
+
+
+def rate(name, G, bytes_per_group, sec, extra=None):
+    d = dict(config=name, groups=G, us_per_launch=sec * 1e6, decisions_per_s=G / sec,
+             alg_bytes_per_group=bytes_per_group, alg_GBps=bytes_per_group * G / sec / 1e9,
+             pct_hbm_peak=100 * bytes_per_group * G / sec / PEAK)
+    if extra:
+        d.update(extra)
+    print(json.dumps(d), flush=True)
+    return d
+
+
+out = []
+
+# C2: 10k groups x 3 peers, commit advance only (latency-bound: 320 KB of state)
+b = synth.gen_commit_small()
+sets = [DeviceBatch(b, dev) for _ in range(4)]
+sec_eager = timed(lambda i: eng.commit_advance(sets[i % 4]), 2000, 100)
+# the eager loop is bound by the Python/ctypes launch path; a HIP graph of 200 launches
+# (captured on the stream the C-ABI launches into) shows the device-side time per launch
+side = torch.cuda.Stream()
+graph = torch.cuda.CUDAGraph()
+with torch.cuda.stream(side):
+    for i in range(8):
+        eng.commit_advance(sets[i % 4])
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=side):
+        for i in range(200):
+            eng.commit_advance(sets[i % 4])
+sec = timed(lambda i: graph.replay(), 20, 3) / 200
+import oracle_lib
+t0 = time.perf_counter()
+for _ in range(50):
+    oracle_lib.commit_advance(*b.commit_args())
+cpu = (time.perf_counter() - t0) / 50
+out.append(rate("C2 10k x 3 commit only (latency-bound)", b.G, 4 * 3 + 20, sec,
+                dict(cpu_oracle_ns_per_group=cpu / b.G * 1e9, cpu_kind="C restatement, 1 thread",
+                     us_per_launch_eager_python=sec_eager * 1e6, timing="HIP graph of 200 launches")))
+
+# C3 and its split kernels: 1M x 5
+G, n, S = 1 << 20, 5, 12
+sets = [DeviceBatch(synth.gen_fused(G, n, seed=77 + s, ld=G + 256), dev) for s in range(S)]
+sec = timed(lambda i: eng.fused_round(sets[i % S]), 300, 30)
+out.append(rate("C3 1M x 5 fused round", G, 137, sec))
+sec = timed(lambda i: eng.vote_tally(sets[i % S]), 300, 30)
+out.append(rate("1M x 5 vote tally only", G, 97, sec))
+sec = timed(lambda i: eng.commit_advance(sets[i % S]), 300, 30)
+out.append(rate("1M x 5 commit advance only", G, 40, sec))
+
+# host-buffer entry point (PCIe and pageable staging inclusive) on one set
+hb = synth.gen_fused(G, n, seed=5)
+with QuorumEngine(max_groups=G, max_slots=n, max_log_terms=int(hb.log_term.size)) as qe:
+    qe.fused_round(*hb.fused_args())
+    t0 = time.perf_counter()
+    for _ in range(3):
+        qe.fused_round(*hb.fused_args())
+    sec = (time.perf_counter() - t0) / 3
+out.append(rate("1M x 5 fused round through rq_fused_round (host buffers, PCIe inclusive)", G, 137, sec))
+del sets
+torch.cuda.empty_cache()
+
+# C4 at one GPU: 8M x 5
+G8 = 8 << 20
+sets = [DeviceBatch(synth.gen_fused(G8, n, seed=300 + s, ld=G8 + 256), dev) for s in range(2)]
+sec = timed(lambda i: eng.fused_round(sets[i % 2]), 40, 5)
+out.append(rate("C4 8M x 5 fused round on ONE GPU (2 sets, 2.8 GB)", G8, 137, sec))
+del sets
+torch.cuda.empty_cache()
+
+# C5: 1M mixed 3-9 + joint, Zipf logs (arena shared between the sets)
+first = synth.gen_mixed(G, seed=500)
+sets = [DeviceBatch(first, dev)]
+for s in range(1, 8):
+    sets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), dev, share_log_with=sets[0]))
+mem = (first.old_mask | first.new_mask).astype(np.int64)
+members = float(sum((mem >> p) & 1 for p in range(16)).mean())
+sec = timed(lambda i: eng.fused_round(sets[i % 8]), 200, 20)
+out.append(rate("C5 1M mixed 3-9 peers + 10% joint, Zipf logs", G, 20 * members + 41, sec,
+                dict(mean_member_slots=members, arena_entries=int(first.log_term.size))))
+del sets
+torch.cuda.empty_cache()
+
+# AppendEntries consistency batch: 1M x 5
+import ctypes as C
+ab = [synth.gen_append(G, n, seed=900 + s) for s in range(6)]
+dab = []
+for b in ab:
+    t = {k: torch.from_numpy(np.ascontiguousarray(b[k].view(np.int32) if b[k].dtype == np.uint32 else
+                                                  (b[k].view(np.int16) if b[k].dtype == np.uint16 else b[k]))).to(dev)
+         for k in ("active_mask", "follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
+                   "flog_off", "flog_term", "match_index", "next_index")}
+    t["ft_out"] = torch.zeros_like(t["follower_term"])
+    t["ok"] = torch.zeros(G, dtype=torch.int16, device=dev); t["sd"] = torch.zeros(G, dtype=torch.int16, device=dev)
+    t["st"] = torch.zeros(G, dtype=torch.uint8, device=dev)
+    dab.append(t)
+
+
+def append_step(i):
+    t = dab[i % len(dab)]
+    p = lambda k: t[k].data_ptr()
+    rc = eng._l.rq_append_check_dev(eng._h, torch.cuda.current_stream().cuda_stream, G, n, G,
+                                    p("active_mask"), p("follower_term"), p("leader_term"), p("prev_log_index"),
+                                    p("prev_log_term"), p("n_new"), p("flog_off"), p("flog_term"), p("ft_out"),
+                                    p("ok"), p("sd"), p("match_index"), p("next_index"), p("st"))
+    assert rc == 0, rc
+
+
+sec = timed(append_step, 200, 20)
+act = float(sum((ab[0].active_mask.astype(np.int64) >> p) & 1 for p in range(n)).mean())
+# per active follower: term, prevIdx, prevTerm, off, gathered term, n_new, match, next in; term', match', next' out
+out.append(rate("AppendEntries consistency batch 1M x 5 (4 followers per group)", G, 44 * act + 4 + 2 + 2 + 2, sec,
+                dict(active_followers=act)))
+
+path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "configs.json")
+os.makedirs(os.path.dirname(path), exist_ok=True)
+json.dump(out, open(path, "w"), indent=1)
+print("wrote", path)
