@@ -48,7 +48,6 @@ def parse():
     ap.add_argument("--what", choices=["fused", "commit", "vote"], default="fused")
     ap.add_argument("--ld-pad", type=int, default=256,
                     help="plane stride = groups + pad (elements): keeps the slot planes off one power-of-two stride")
-    ap.add_argument("--skew", type=int, default=-1, help="one slab per set, arrays skewed by this many bytes (-1: separate allocations)")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
     ap.add_argument("--summary", choices=["u16", "i32"], default="u16",
                     help="commit summary on the wire: 16-bit window with escape (default) or full int32")
@@ -148,8 +147,6 @@ def main():
         elif ex is not None:
             kw.update(commit_lo16=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R),
                       summary_escapes=escape_counter)
-        if args.skew >= 0:
-            kw["skew_bytes"] = args.skew
         sets.append(DeviceBatch(b, device, **kw))
     if args.workload == "fused":
         bytes_per_group = alg_bytes_per_group(n, args.what)
@@ -234,7 +231,7 @@ def main():
                        "summary_mode": args.summary if ex is not None else None,
                        "summary_impl": ex.impl if ex is not None else None,
                        "rounds_per_allgather": R if ex is not None else None,
-                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "skew": args.skew,
+                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad,
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -10,7 +10,6 @@ struct rq_round_args {
     uint32_t G;
     uint32_t ld;
     uint32_t m;  // joint kernels: number of slot planes
-    uint32_t gather_policy;  // set by rq_launch_round from the variant word
     // commit side (Node.matchIndex / commitIndex / currentTerm / log, raft.go:35-68)
     const int32_t  *match;
     const int32_t  *commit;
@@ -47,7 +46,8 @@ struct rq_round_args {
 //   bits 0-3  groups per thread V: 1, 2 or 4 (0 = 1)
 //   bit  4    non-temporal loads of the streamed planes
 //   bit  5    non-temporal stores of the outputs
-//   bits 6-7  cache policy of the log-term gather: 0 plain, 1 nt, 2 sc1, 3 sc0 sc1
+//   bit  6    non-temporal log-term gather (only with bits 4 and 5)
+//   bit  7    fused round, V = 1: stage the block's log-arena slice through LDS
 //   bits 8-11 threads per block / 64: 1..4 (0 = 256 threads)
 // Measured on MI355X at 1M groups x 5 slots: one group per thread in
 // 128-thread blocks with non-temporal loads and stores is the fastest fused
@@ -57,6 +57,8 @@ struct rq_round_args {
 #define RQ_VAR_V_MASK   0x0F
 #define RQ_VAR_NT_LOAD  0x10
 #define RQ_VAR_NT_STORE 0x20
+#define RQ_VAR_NT_GATHER 0x40  // honoured together with both bits above
+#define RQ_VAR_LDS_LOG  0x80
 #define RQ_VAR_DEFAULT_FIXED 0x271
 #define RQ_VAR_DEFAULT_JOINT 0x131
 

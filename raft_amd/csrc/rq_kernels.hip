@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kLdsLogCap = 4096;  // int32 entries of log arena staged per block (16 KiB)
 
 // ---------------------------------------------------------------------------
 // vector load/store helpers
@@ -217,16 +218,13 @@ __device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32
 
 constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02;
 
-// The one dependent, data-indexed load of a round: log[N].TermNum.  `policy`
-// is wave-uniform (kernel argument): 0 plain, 1 non-temporal, 2 agent-scope
-// (sc1), 3 system-scope (sc0 sc1).
-__device__ __forceinline__ int32_t gather_term(const int32_t *p, uint32_t policy) {
-    switch (policy) {
-    case 1: return __builtin_nontemporal_load(p);
-    case 2: return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    case 3: return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    default: return *p;
-    }
+// The one dependent, data-indexed load of a round: log[N].TermNum.  The cache
+// policy is a compile-time choice: with a run-time flag the compiler merges
+// the two loads and drops the non-temporal hint.
+template <bool NT>
+__device__ __forceinline__ int32_t gather_term(const int32_t *p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
 }
 
 // 16-bit window of the commit summary: offset from a per-group base, 65535 =
@@ -253,7 +251,8 @@ __device__ __forceinline__ void store_commit_lo16(const rq_round_args &a, uint32
 // ---------------------------------------------------------------------------
 template <int N, int V, int WHAT, int FLAGS, bool FULL>
 __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
-                                                     uint32_t g0, int valid) {
+                                                     uint32_t g0, int valid,
+                                                     const int32_t *lds_log, uint32_t lds_seg0) {
     constexpr bool NTL = (FLAGS & RQ_VAR_NT_LOAD) != 0;
     constexpr bool NTS = (FLAGS & RQ_VAR_NT_STORE) != 0;
     constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
@@ -307,7 +306,12 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
             adv[k] = (k < valid) && nq[k] > cm[k];
             inb[k] = (uint32_t)nq[k] < len;
             gt[k] = 0;
-            if (adv[k] && inb[k]) gt[k] = gather_term(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]), a.gather_policy);
+            if (adv[k] && inb[k]) {
+                if ((FLAGS & RQ_VAR_LDS_LOG) && lds_log)   // the block's arena segment is in LDS
+                    gt[k] = lds_log[(uint32_t)off[k] - lds_seg0 + (uint32_t)nq[k]];
+                else
+                    gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]));
+            }
         }
     }
 
@@ -361,11 +365,32 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
 template <int N, int V, int WHAT, int FLAGS>
 __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args a) {
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+    const int32_t *lds_log = nullptr;
+    uint32_t lds_seg0 = 0;
+    if constexpr ((FLAGS & RQ_VAR_LDS_LOG) != 0 && (WHAT & RQ_WHAT_COMMIT) != 0) {
+        // Stage the block's contiguous slice of the log arena (groups are in CSR
+        // order) through LDS with coalesced loads; the per-group log[N] lookup
+        // then reads LDS.  Blocks whose slice exceeds the buffer gather from
+        // global memory as usual.  All conditions here are block-uniform.
+        __shared__ int32_t staged[kLdsLogCap];
+        const uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x * V;
+        if (b0 < a.G) {
+            const uint64_t b1 = min(b0 + (uint64_t)blockDim.x * V, (uint64_t)a.G);
+            const uint32_t s0 = a.log_off[b0], s1 = a.log_off[b1];
+            if (s1 - s0 <= (uint32_t)kLdsLogCap) {
+                for (uint32_t i = threadIdx.x; i < s1 - s0; i += blockDim.x)
+                    staged[i] = __builtin_nontemporal_load(a.log_term + s0 + i);
+                lds_log = staged;
+                lds_seg0 = s0;
+            }
+        }
+        __syncthreads();
+    }
     uint32_t el_field = 0;
     if (g0 + V <= a.G)
-        el_field = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V);
+        el_field = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, lds_log, lds_seg0);
     else if (g0 < a.G)
-        el_field = round_fixed_body<N, V, WHAT, FLAGS, false>(a, (uint32_t)g0, (int)(a.G - g0));
+        el_field = round_fixed_body<N, V, WHAT, FLAGS, false>(a, (uint32_t)g0, (int)(a.G - g0), lds_log, lds_seg0);
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
         if (a.elected_bits) pack_elected<V>(el_field, g0, a.G, a.elected_bits);
     }
@@ -570,7 +595,7 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
             adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
             inb[k] = (uint32_t)nq[k] < len;
             gt[k] = 0;
-            if (adv[k] && inb[k]) gt[k] = gather_term(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]), a.gather_policy);
+            if (adv[k] && inb[k]) gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]));
         }
     }
 
@@ -745,12 +770,20 @@ hipError_t launch_fixed(const rq_round_args &a, uint32_t block, hipStream_t s) {
 template <int N, int V, int WHAT>
 hipError_t launch_fixed_flags(const rq_round_args &a, int flags, uint32_t block, hipStream_t s) {
     constexpr int kNt = RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE;
-    // the single-policy builds exist for the fused round only (tuning knobs);
-    // the split kernels come in "all non-temporal" and "all default" builds
+    constexpr int kNtAll = kNt | RQ_VAR_NT_GATHER;
+    constexpr bool kCommit = (WHAT & RQ_WHAT_COMMIT) != 0;
+    // Builds: every kernel comes as "default policy" and "all non-temporal"
+    // (the gather bit only where there is a gather); the fused round also
+    // has the single-policy builds and the LDS-staged gather as tuning knobs.
     if constexpr (WHAT != (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) {
-        if ((flags & kNt) == kNt) return launch_fixed<N, V, WHAT, kNt>(a, block, s);
-        return launch_fixed<N, V, WHAT, 0>(a, block, s);
+        if ((flags & kNt) != kNt) return launch_fixed<N, V, WHAT, 0>(a, block, s);
+        if constexpr (kCommit)
+            if (flags & RQ_VAR_NT_GATHER) return launch_fixed<N, V, WHAT, kNtAll>(a, block, s);
+        return launch_fixed<N, V, WHAT, kNt>(a, block, s);
     } else {
+        if constexpr (V == 1)
+            if (flags & RQ_VAR_LDS_LOG) return launch_fixed<N, V, WHAT, kNt | RQ_VAR_LDS_LOG>(a, block, s);
+        if ((flags & kNtAll) == kNtAll) return launch_fixed<N, V, WHAT, kNtAll>(a, block, s);
         switch (flags & kNt) {
         case 0: return launch_fixed<N, V, WHAT, 0>(a, block, s);
         case RQ_VAR_NT_LOAD: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD>(a, block, s);
@@ -846,9 +879,8 @@ hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, in
     if (args.G > 0x7FFFFFFFu || args.ld < args.G) return hipErrorInvalidValue;
     if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
     if (variant == 0) variant = joint || n > 9 ? RQ_VAR_DEFAULT_JOINT : RQ_VAR_DEFAULT_FIXED;
-    rq_round_args a = args;
-    a.gather_policy = (uint32_t)(variant >> 6) & 3u;
-    const int flags = variant & 0x30;
+    const rq_round_args &a = args;
+    const int flags = variant & (RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE | RQ_VAR_NT_GATHER | RQ_VAR_LDS_LOG);
     int want = variant & RQ_VAR_V_MASK;
     if (want == 0) want = 1;
     if (want != 1 && want != 2 && want != 4) return hipErrorInvalidValue;

@@ -27,14 +27,9 @@ class DeviceBatch:
                "voter_term", "voted_for", "last_log_term", "cand_term", "cand_id")
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
-                 skew_bytes=None, share_log_with=None, commit_lo16=None, summary_escapes=None,
-                 summary_base=None):
+                 share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
-        skew_bytes: if not None, every array is carved from ONE device slab and
-        consecutive arrays are offset by an extra skew_bytes, so that the ~26
-        concurrently streamed arrays do not all sit at the same offset modulo a
-        large power of two (HBM channel/bank aliasing).
         share_log_with: another DeviceBatch whose log_off/log_term device arrays
         are reused (the batch must have been generated with the same logs)."""
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
@@ -59,31 +54,10 @@ class DeviceBatch:
                 ("elected", (G,), torch.uint8), ("max_term", (G,), torch.int32),
                 ("status", (G,), torch.uint8), ("elected_bits", ((G + 63) // 64,), torch.int64)]
         self.t, o = {}, {}
-        if skew_bytes is None:
-            for k, a in host.items():
-                self.t[k] = torch.from_numpy(a).to(self.device)
-            for k, shape, dt in outs:
-                o[k] = torch.zeros(shape, dtype=dt, device=self.device)
-        else:
-            np2t = {np.dtype(np.int32): torch.int32, np.dtype(np.int16): torch.int16}
-            plan, off = [], 0
-            for k, a in host.items():
-                plan.append((k, off, a.shape, np2t[a.dtype], a))
-                off += (a.nbytes + 255) // 256 * 256 + skew_bytes
-            for k, shape, dt in outs:
-                nbytes = int(np.prod(shape)) * torch.empty(0, dtype=dt).element_size()
-                plan.append((k, off, shape, dt, None))
-                off += (nbytes + 255) // 256 * 256 + skew_bytes
-            self.slab = torch.zeros(off + 256, dtype=torch.uint8, device=self.device)
-            for k, o0, shape, dt, a in plan:
-                cnt = int(np.prod(shape))
-                esz = torch.empty(0, dtype=dt).element_size()
-                v = self.slab[o0:o0 + cnt * esz].view(dt).view(shape)
-                if a is not None:
-                    v.copy_(torch.from_numpy(a))
-                    self.t[k] = v
-                else:
-                    o[k] = v
+        for k, a in host.items():
+            self.t[k] = torch.from_numpy(a).to(self.device)
+        for k, shape, dt in outs:
+            o[k] = torch.zeros(shape, dtype=dt, device=self.device)
         if share_log_with is not None:
             self.t["log_off"] = share_log_with.t["log_off"]
             self.t["log_term"] = share_log_with.t["log_term"]

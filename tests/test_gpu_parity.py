@@ -218,7 +218,7 @@ def _check_dev(res, exp, G, members=None):
     assert not np.unpackbits(res["elected_bits"].view(np.uint8), bitorder="little")[G:].any()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 0x14, 0x24, 0x34, 0x31, 0x32, 0x231, 0x134, 0x412])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 0x14, 0x24, 0x34, 0x31, 0x32, 0x231, 0x134, 0x412, 0x2b1, 0x1f1])
 def test_device_launch_variants(dev, variant):
     from raft_amd.device import DeviceBatch
     for n in (3, 5, 9):
