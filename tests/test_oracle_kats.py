@@ -342,3 +342,43 @@ def test_append_check_batch_semantics():
                        active_mask=[0b0100])
     assert r.follower_term[:, 0].tolist() == [3, 1, 2, 0] and r.success_mask[0] == 0b0100
     assert r.next_index[:, 0].tolist() == [3, 3, 4, 3] and r.status[0] == 0
+
+
+def test_joint_oracle_equals_numpy_closed_form():
+    """Joint-consensus oracle (member masks, majority in both configurations)
+    against an independent numpy formulation, random masks and adversarial values."""
+    from raft_amd import synth
+    rng = np.random.default_rng(23)
+    for m in (1, 2, 3, 5, 8, 11, 16):
+        G = 3000
+        b = synth.gen_adversarial(G, m, seed=700 + m)
+        lim = (1 << m) - 1
+        om = rng.integers(1, lim + 1, G).astype(np.uint16)
+        nm = np.where(rng.random(G) < 0.5, om, rng.integers(1, lim + 1, G)).astype(np.uint16)
+        r = o.fused_round(*b.fused_args(), old_mask=om, new_mask=nm)
+        slots = np.arange(m)[:, None]
+        in_old = ((om[None, :].astype(np.int64) >> slots) & 1).astype(bool)
+        in_new = ((nm[None, :].astype(np.int64) >> slots) & 1).astype(bool)
+        member = in_old | in_new
+        # commit: min of the two configurations' quorum indices
+        N = np.minimum(synth.masked_quorum_index(b.match, om), synth.masked_quorum_index(b.match, nm))
+        lens = np.diff(b.log_off.astype(np.int64))
+        adv = N > b.commit
+        inb = (N >= 0) & (N < lens)
+        idx = np.where(adv & inb, b.log_off[:-1].astype(np.int64) + N, 0)
+        tat = b.log_term[idx] if b.log_term.size else np.zeros_like(idx)
+        assert np.array_equal(r.commit, np.where(adv & inb & (tat == b.leader_term), N, b.commit).astype(np.int32))
+        # vote: predicate on members only, majority in both configurations
+        vt, vf, ll = (x.astype(np.int64) for x in (b.voter_term, b.voted_for, b.last_log_term))
+        t, cid = b.cand_term.astype(np.int64)[None, :], b.cand_id.astype(np.int64)[None, :]
+        empty = ll == synth.LOG_EMPTY
+        grant = member & (t >= vt) & ((vf == -1) | (vf == cid)) & ~empty & (ll <= t)
+        bits = (1 << np.arange(m))[:, None]
+        assert np.array_equal(r.grant_mask, (grant * bits).sum(0).astype(np.uint16))
+        assert np.array_equal(r.stepdown_mask, ((member & (t > vt)) * bits).sum(0).astype(np.uint16))
+        mx = np.where(member, np.maximum(vt, t), np.iinfo(np.int64).min).max(0)
+        assert np.array_equal(r.max_term, mx.astype(np.int32))
+        el = (2 * (grant & in_old).sum(0) > in_old.sum(0)) & (2 * (grant & in_new).sum(0) > in_new.sum(0)) & (mx == t[0])
+        assert np.array_equal(r.elected.astype(bool), el)
+        assert np.array_equal(r.voter_term[member], np.maximum(vt, t)[member].astype(np.int32))
+        assert np.array_equal(r.voter_term[~member], b.voter_term[~member])
