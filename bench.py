@@ -235,7 +235,8 @@ def main():
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kernel_ms, "kernel": "rq_round_fixed<%d,...>" % n},
+                         "kernel_ms": kernel_ms,
+                         "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else "rq_round_joint<16,...>"},
             "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "fused":
