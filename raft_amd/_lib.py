@@ -50,6 +50,9 @@ PROTOTYPES = {
     "rq_commit_advance_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 7,
     "rq_vote_tally_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 12,
     "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 23,
+    "rq_plan_fused_round": [vp, cint, cint, u32, u32, u32] + [vp] * 23 + [C.POINTER(vp)],
+    "rq_plan_launch": [vp, vp],
+    "rq_plan_destroy": [vp],
     "rq_stream_sync": [vp, vp],
     "rq_comm_unique_id": [u8p],
     "rq_comm_create": [cint, u8p, cint, cint, u32, C.POINTER(vp)],

@@ -9,6 +9,14 @@
 #include <mutex>
 #include <new>
 
+struct rq_plan {
+    rq_engine *engine;
+    rq_round_args args;
+    uint32_t n;
+    bool joint;
+    int variant;
+};
+
 struct rq_engine {
     int device = 0;
     uint32_t max_groups = 0, max_slots = 0, ld = 0;
@@ -708,6 +716,60 @@ int rq_copy_from_device(rq_engine *e, void *dst, const void *src, uint64_t bytes
     if (!e || (bytes && (!dst || !src))) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
     if (bytes) RQ_HIP(e, hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return RQ_OK;
+}
+
+int rq_plan_fused_round(rq_engine *e, int variant, int joint, uint32_t G, uint32_t n, uint32_t ld,
+                        const uint16_t *old_mask, const uint16_t *new_mask,
+                        const int32_t *match, const int32_t *commit, const int32_t *leader_term,
+                        const uint32_t *log_off, const int32_t *log_term,
+                        const int32_t *voter_term, const int32_t *voted_for,
+                        const int32_t *voter_last_log_term, const int32_t *cand_term,
+                        const int32_t *cand_id, int32_t *commit_out, int32_t *voter_term_out,
+                        uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
+                        int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
+                        uint16_t *commit_lo16, const int32_t *summary_base,
+                        uint32_t *summary_escapes, rq_plan **out) {
+    if (!e || !out) return RQ_E_ARG;
+    *out = nullptr;
+    rq_round_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.m = n;
+    a.old_mask = joint ? old_mask : nullptr; a.new_mask = joint ? new_mask : nullptr;
+    a.match = match; a.commit = commit; a.leader_term = leader_term;
+    a.log_off = log_off; a.log_term = log_term;
+    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
+    a.cand_term = cand_term; a.cand_id = cand_id;
+    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
+    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
+    a.status_out = status_out; a.elected_bits = elected_bits;
+    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
+    if (n < 1 || n > RQ_MAX_SLOTS || ld < G || G > 0x7FFFFFFFu) return RQ_E_ARG;
+    if (!match || !commit || !leader_term || !log_off || !log_term || !commit_out || !voter_term ||
+        !voted_for || !voter_last_log_term || !cand_term || !cand_id || !voter_term_out ||
+        !grant_mask || !stepdown_mask || !elected || !max_term)
+        return RQ_E_ARG;
+    if (joint && (!old_mask || !new_mask)) return RQ_E_ARG;
+    rq_plan *p = new (std::nothrow) rq_plan{e, a, n, joint != 0, variant};
+    if (!p) return RQ_E_NOMEM;
+    *out = p;
+    return RQ_OK;
+}
+
+int rq_plan_launch(rq_plan *p, void *stream) {
+    if (!p) return RQ_E_ARG;
+    rq_engine *e = p->engine;
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipError_t err = rq_launch_round(p->args, p->n, p->joint, RQ_WHAT_COMMIT | RQ_WHAT_VOTE,
+                                     p->variant, (hipStream_t)stream);
+    if (err == hipErrorInvalidValue) return RQ_E_ARG;
+    RQ_HIP(e, err);
+    return RQ_OK;
+}
+
+int rq_plan_destroy(rq_plan *p) {
+    if (!p) return RQ_E_ARG;
+    delete p;
     return RQ_OK;
 }
 

@@ -79,6 +79,11 @@ class DeviceBatch:
         self.summary_base = summary_base
         self.o = o
         self._args = {}
+        self._plans = []
+
+    def __del__(self):
+        for l, plan in getattr(self, "_plans", []):
+            l.rq_plan_destroy(plan)
 
     def bytes_resident(self):
         return sum(x.numel() * x.element_size() for x in list(self.t.values()) + list(self.o.values())
@@ -147,25 +152,47 @@ class DeviceEngine:
                     "rq_copy_from_device")
 
     def fused_round(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
-        """Enqueue one fused round for DeviceBatch b on torch's current stream."""
-        key = (want_bits, status)
-        tail = b._args.get(key)
-        if tail is None:                      # pointer marshalling is done once per batch
+        """Enqueue one fused round for DeviceBatch b on torch's current stream.
+        The argument set is validated once into an rq_plan per (batch, options);
+        every later call is a two-argument rq_plan_launch."""
+        key = (variant, want_bits, status)
+        plan = b._args.get(key)
+        if plan is None:
+            import ctypes as C
             t, o = b.t, b.o
-            p = lambda x: x.data_ptr()
-            tail = [p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
-                    p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
-                    p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
-                    p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
-                    p(o["elected_bits"]) if want_bits else None,
-                    p(o["commit_lo16"]) if o["commit_lo16"] is not None else None,
-                    p(b.summary_base) if b.summary_base is not None else None,
-                    p(o["summary_escapes"]) if o["summary_escapes"] is not None else None]
-            if b.joint:
-                tail = [p(t["old_mask"]), p(t["new_mask"])] + tail
-            b._args[key] = tail
+            p = lambda x: None if x is None else x.data_ptr()
+            plan = C.c_void_p()
+            rc = self._l.rq_plan_fused_round(
+                self._h, variant, 1 if b.joint else 0, b.G, b.n, b.ld,
+                p(t.get("old_mask")), p(t.get("new_mask")),
+                p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
+                p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
+                p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
+                p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
+                p(o["elected_bits"]) if want_bits else None,
+                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]), C.byref(plan))
+            if rc != 0:
+                self._check(rc, "rq_plan_fused_round")
+            b._args[key] = plan
+            b._plans.append((self._l, plan))
+        rc = self._l.rq_plan_launch(plan, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            self._check(rc, "rq_plan_launch")
+
+    def fused_round_direct(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """The same round through rq_fused_round_dev / rq_fused_round_joint_dev (all
+        arguments marshalled on every call)."""
+        t, o = b.t, b.o
+        p = lambda x: None if x is None else x.data_ptr()
+        tail = [p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
+                p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
+                p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
+                p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
+                p(o["elected_bits"]) if want_bits else None,
+                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"])]
         if b.joint:
-            rc = self._l.rq_fused_round_joint_dev(self._h, self._stream(), variant, b.G, b.n, b.ld, *tail)
+            rc = self._l.rq_fused_round_joint_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
+                                                  p(t["old_mask"]), p(t["new_mask"]), *tail)
         else:
             rc = self._l.rq_fused_round_dev(self._h, self._stream(), variant, b.G, b.n, b.ld, *tail)
         if rc != 0:

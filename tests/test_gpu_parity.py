@@ -447,3 +447,18 @@ def test_native_rccl_summary_allgather_one_rank(dev):
             assert torch.equal(send[s], recv[s])
     finally:
         assert l.rq_comm_destroy(h) == 0
+
+
+def test_plan_launch_equals_direct_launch(dev):
+    """rq_plan_* (validated once, launched many times) and the per-call
+    rq_fused_round_dev / rq_fused_round_joint_dev path give identical outputs."""
+    from raft_amd.device import DeviceBatch
+    for b, kw in ((synth.gen_adversarial(33333, 7, seed=2), {}),
+                  (synth.gen_mixed(20000, seed=6), {})):
+        a, d = DeviceBatch(b), DeviceBatch(b)
+        for _ in range(3):
+            dev.fused_round(a)
+        dev.fused_round_direct(d)
+        ra, rd = a.results(), d.results()
+        for k in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status", "elected_bits"):
+            assert np.array_equal(ra[k], rd[k]), k
