@@ -66,7 +66,7 @@ __device__ __forceinline__ void st_u16(uint16_t *p, int valid, const uint32_t (&
 #pragma unroll
         for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint16_t)r[k];
     } else if constexpr (V == 1) {
-        *p = (uint16_t)r[0];
+        if (NT) __builtin_nontemporal_store((uint16_t)r[0], p); else *p = (uint16_t)r[0];
     } else if constexpr (V == 2) {
         uint32_t w = (r[0] & 0xFFFFu) | (r[1] << 16);
         uint32_t *wp = reinterpret_cast<uint32_t *>(p);
@@ -88,9 +88,11 @@ __device__ __forceinline__ void st_u8(uint8_t *p, int valid, const uint32_t (&r)
 #pragma unroll
         for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint8_t)r[k];
     } else if constexpr (V == 1) {
-        *p = (uint8_t)r[0];
+        if (NT) __builtin_nontemporal_store((uint8_t)r[0], p); else *p = (uint8_t)r[0];
     } else if constexpr (V == 2) {
-        *reinterpret_cast<uint16_t *>(p) = (uint16_t)((r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8));
+        const uint16_t w = (uint16_t)((r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8));
+        uint16_t *wp = reinterpret_cast<uint16_t *>(p);
+        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
     } else {
         uint32_t w = (r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8) | ((r[2] & 0xFFu) << 16) | (r[3] << 24);
         uint32_t *wp = reinterpret_cast<uint32_t *>(p);
@@ -191,12 +193,14 @@ __device__ __forceinline__ void vote_slot(int32_t cur, int32_t vf, int32_t llt,
                                           int32_t term, int32_t cid, int32_t &cur2,
                                           uint32_t &stepdown, uint32_t &grant,
                                           uint32_t &panic) {
-    stepdown = term > cur;
+    // bitwise on purpose: && / || compile to a chain of divergent branches
+    stepdown = (uint32_t)(term > cur);
     cur2 = max(cur, term);
-    const bool reach = term >= cur;
-    const bool empty = llt == INT_MIN;
-    panic = reach && empty;
-    grant = reach && (vf == -1 || vf == cid) && !empty && (llt <= term);
+    const uint32_t reach = (uint32_t)(term >= cur);
+    const uint32_t empty = (uint32_t)(llt == INT_MIN);
+    const uint32_t free_vote = (uint32_t)(vf == -1) | (uint32_t)(vf == cid);
+    panic = reach & empty;
+    grant = reach & free_vote & (empty ^ 1u) & (uint32_t)(llt <= term);
 }
 
 // Pack each thread's V elected bits (groups g0..g0+V-1) into the 1-bit-per-
