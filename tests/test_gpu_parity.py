@@ -462,3 +462,40 @@ def test_plan_launch_equals_direct_launch(dev):
         ra, rd = a.results(), d.results()
         for k in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status", "elected_bits"):
             assert np.array_equal(ra[k], rd[k]), k
+
+
+def test_plane_offsets_beyond_4_gib(dev):
+    """Plane stride so large that slot 4 starts more than 4 GiB into each plane
+    array: byte offsets must be computed in 64 bits."""
+    import torch
+    G, n, ld = 5000, 5, (1 << 28) + 64
+    b = synth.gen_adversarial(G, n, seed=31)
+    exp = o.fused_round(*b.fused_args())
+    d = "cuda:0"
+    planes = {}
+    for k in ("match", "voter_term", "voted_for", "last_log_term"):
+        t = torch.zeros((n, ld), dtype=torch.int32, device=d)
+        t[:, :G] = torch.from_numpy(b[k]).to(d)
+        planes[k] = t
+    vt_out = torch.zeros((n, ld), dtype=torch.int32, device=d)
+    vec = {k: torch.from_numpy(b[k].view(np.int32) if b[k].dtype == np.uint32 else b[k]).to(d)
+           for k in ("commit", "leader_term", "log_off", "log_term", "cand_term", "cand_id")}
+    out = dict(commit=torch.zeros(G, dtype=torch.int32, device=d), grant=torch.zeros(G, dtype=torch.int16, device=d),
+               sd=torch.zeros(G, dtype=torch.int16, device=d), el=torch.zeros(G, dtype=torch.uint8, device=d),
+               mx=torch.zeros(G, dtype=torch.int32, device=d), st=torch.zeros(G, dtype=torch.uint8, device=d))
+    p = lambda t: t.data_ptr()
+    for variant in (0, 0x234):
+        rc = dev._l.rq_fused_round_dev(dev._h, torch.cuda.current_stream().cuda_stream, variant, G, n, ld,
+                                       p(planes["match"]), p(vec["commit"]), p(vec["leader_term"]), p(vec["log_off"]),
+                                       p(vec["log_term"]), p(planes["voter_term"]), p(planes["voted_for"]),
+                                       p(planes["last_log_term"]), p(vec["cand_term"]), p(vec["cand_id"]),
+                                       p(out["commit"]), p(vt_out), p(out["grant"]), p(out["sd"]), p(out["el"]),
+                                       p(out["mx"]), p(out["st"]), None, None, None, None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert np.array_equal(out["commit"].cpu().numpy(), exp.commit)
+        assert np.array_equal(vt_out[:, :G].cpu().numpy(), exp.voter_term)
+        assert np.array_equal(out["grant"].cpu().numpy().view(np.uint16), exp.grant_mask)
+        assert np.array_equal(out["el"].cpu().numpy(), exp.elected)
+        assert np.array_equal(out["st"].cpu().numpy(), exp.status)
+        vt_out.zero_()
