@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Times every BASELINE configuration that fits one GPU, plus the split
+"""Times every benchmark configuration that fits one GPU, plus the split
 kernels and the host-buffer (PCIe-inclusive) entry point, and writes one JSON
 document.  Run on the MI355X box:  python tools/config_report.py [out.json]
 
