@@ -202,7 +202,8 @@ int rq_append_check(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
 /* rq_upload copies one round's inputs (same arguments as rq_fused_round's
  * inputs) into the engine's device buffers; rq_step runs `rounds` fused
  * rounds on them with no host transfer (voter terms and commitIndex are
- * updated in place, as the Go host would apply them); rq_download copies the
+ * updated in place, as the Go host would apply them; 8 or more rounds are
+ * captured once into a HIP graph and replayed); rq_download copies the
  * current outputs back (voter_term_out dense, [n][G]).  Any output pointer may
  * be NULL to skip it. */
 int rq_upload(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,

@@ -40,6 +40,10 @@ struct rq_engine {
     // resident round (rq_upload / rq_step / rq_download)
     bool resident = false;
     uint32_t res_G = 0, res_n = 0;
+    // rq_step(rounds >= kGraphMinRounds): the rounds are captured once into a HIP
+    // graph (a launch-bound inner loop when a round is only microseconds long)
+    hipGraphExec_t step_graph = nullptr;
+    uint32_t graph_G = 0, graph_n = 0, graph_rounds = 0;
 };
 
 namespace {
@@ -294,6 +298,7 @@ int rq_engine_destroy(rq_engine *e) {
         }
         if (e->slab && hipFree(e->slab) != hipSuccess) rc = RQ_E_HIP;
         if (e->aux && hipFree(e->aux) != hipSuccess) rc = RQ_E_HIP;
+        if (e->step_graph) (void)hipGraphExecDestroy(e->step_graph);
     }
     delete e;
     return rc;
@@ -558,8 +563,30 @@ int rq_step(rq_engine *e, uint32_t rounds) {
     RQ_HIP(e, hipSetDevice(e->device));
     if (e->res_G == 0) return RQ_OK;
     rq_round_args a = device_args(e, e->res_G, e->res_n, false);
-    for (uint32_t r = 0; r < rounds; r++)
-        RQ_HIP(e, rq_launch_round(a, e->res_n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, 0, e->stream));
+    constexpr uint32_t kGraphMinRounds = 8;
+    if (rounds >= kGraphMinRounds) {
+        if (e->step_graph && (e->graph_G != e->res_G || e->graph_n != e->res_n || e->graph_rounds != rounds)) {
+            (void)hipGraphExecDestroy(e->step_graph);
+            e->step_graph = nullptr;
+        }
+        if (!e->step_graph) {
+            hipGraph_t g = nullptr;
+            RQ_HIP(e, hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal));
+            hipError_t err = hipSuccess;
+            for (uint32_t r = 0; r < rounds && err == hipSuccess; r++)
+                err = rq_launch_round(a, e->res_n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, 0, e->stream);
+            hipError_t end = hipStreamEndCapture(e->stream, &g);
+            if (err == hipSuccess) err = end;
+            if (err == hipSuccess) err = hipGraphInstantiate(&e->step_graph, g, nullptr, nullptr, 0);
+            if (g) (void)hipGraphDestroy(g);
+            if (err != hipSuccess) { e->step_graph = nullptr; RQ_HIP(e, err); }
+            e->graph_G = e->res_G; e->graph_n = e->res_n; e->graph_rounds = rounds;
+        }
+        RQ_HIP(e, hipGraphLaunch(e->step_graph, e->stream));
+    } else {
+        for (uint32_t r = 0; r < rounds; r++)
+            RQ_HIP(e, rq_launch_round(a, e->res_n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, 0, e->stream));
+    }
     RQ_HIP(e, hipStreamSynchronize(e->stream));
     return RQ_OK;
 }

@@ -279,6 +279,21 @@ def test_upload_step_download(engine):
     engine.step(3)                      # further rounds on applied state change nothing
     r2 = engine.download()
     assert np.array_equal(r2.commit, r.commit) and np.array_equal(r2.voter_term, r.voter_term)
+    # many rounds go through a captured HIP graph: same fixed point, and fresh state works after it
+    import time
+    small = synth.gen_commit_small()
+    engine.upload(*small.fused_args())
+    t0 = time.perf_counter(); engine.step(64); engine.step(64); t1 = time.perf_counter()
+    rs = engine.download()
+    es = o.fused_round(*small.fused_args())
+    assert np.array_equal(rs.commit, es.commit) and np.array_equal(rs.voter_term, es.voter_term)
+    assert np.array_equal(rs.elected, o.fused_round(small.match, es.commit, small.leader_term, small.log_off,
+                                                    small.log_term, es.voter_term, small.voted_for,
+                                                    small.last_log_term, small.cand_term, small.cand_id).elected)
+    assert t1 - t0 < 1.0
+    engine.upload(*b.fused_args())
+    engine.step(9)                      # a different shape invalidates the cached graph
+    assert np.array_equal(engine.download().commit, exp.commit)
 
 
 # ---------------------------------------------------------------------------
