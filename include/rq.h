@@ -326,6 +326,12 @@ int rq_stream_sync(rq_engine *e, void *stream);
 #define RQ_MEM_FINEGRAINED 1
 #define RQ_MEM_UNCACHED    2
 int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out);
+/* Page-locked host memory for the buffers handed to the host-buffer entry
+ * points: copies from it run at the PCIe rate instead of being staged through
+ * the runtime's bounce buffers (a Go host keeps its flat slices here, outside
+ * the Go heap, so nothing is pinned by cgo either). */
+int rq_host_alloc(rq_engine *e, uint64_t bytes, void **out);
+int rq_host_free(rq_engine *e, void *ptr);
 int rq_device_free(rq_engine *e, void *ptr);
 int rq_copy_to_device(rq_engine *e, void *dst, const void *src, uint64_t bytes);
 int rq_copy_from_device(rq_engine *e, void *dst, const void *src, uint64_t bytes);

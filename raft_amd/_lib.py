@@ -63,6 +63,8 @@ PROTOTYPES = {
     "rq_comm_last_error": [vp, C.POINTER(cint), C.POINTER(cint)],
     "rq_device_alloc": [vp, u64, cint, C.POINTER(vp)],
     "rq_device_free": [vp, vp],
+    "rq_host_alloc": [vp, u64, C.POINTER(vp)],
+    "rq_host_free": [vp, vp],
     "rq_copy_to_device": [vp, vp, vp, u64],
     "rq_copy_from_device": [vp, vp, vp, u64],
 }

@@ -724,6 +724,23 @@ int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out) {
     return RQ_OK;
 }
 
+int rq_host_alloc(rq_engine *e, uint64_t bytes, void **out) {
+    if (!e || !out || bytes == 0) return RQ_E_ARG;
+    *out = nullptr;
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipError_t err = hipHostMalloc(out, (size_t)bytes, hipHostMallocDefault);
+    if (err != hipSuccess) { e->last_hip.store((int)err); *out = nullptr; return RQ_E_NOMEM; }
+    return RQ_OK;
+}
+
+int rq_host_free(rq_engine *e, void *ptr) {
+    if (!e) return RQ_E_ARG;
+    if (!ptr) return RQ_OK;
+    RQ_HIP(e, hipSetDevice(e->device));
+    RQ_HIP(e, hipHostFree(ptr));
+    return RQ_OK;
+}
+
 int rq_device_free(rq_engine *e, void *ptr) {
     if (!e) return RQ_E_ARG;
     if (!ptr) return RQ_OK;

@@ -60,6 +60,9 @@ class QuorumEngine:
     # -- lifetime ---------------------------------------------------------
     def close(self):
         if getattr(self, "_h", None):
+            for p in getattr(self, "_pinned", []):
+                self._l.rq_host_free(self._h, p)
+            self._pinned = []
             self._l.rq_engine_destroy(self._h)
             self._h = None
 
@@ -82,6 +85,19 @@ class QuorumEngine:
     def _check(self, rc, where):
         if rc != 0:
             raise RqError(rc, where, self._l.rq_last_hip_error(self._h))
+
+    def pinned_like(self, array):
+        """A copy of `array` in page-locked host memory obtained from rq_host_alloc
+        (numpy view over it; freed with the engine)."""
+        a = np.ascontiguousarray(array)
+        p = C.c_void_p()
+        self._check(self._l.rq_host_alloc(self._h, max(a.nbytes, 8), C.byref(p)), "rq_host_alloc")
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p)
+        buf = (C.c_uint8 * max(a.nbytes, 8)).from_address(p.value)
+        out = np.frombuffer(buf, dtype=a.dtype, count=a.size).reshape(a.shape)
+        out[...] = a
+        return out
 
     # -- helpers ----------------------------------------------------------
     @staticmethod

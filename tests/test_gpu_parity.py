@@ -514,3 +514,12 @@ def test_plane_offsets_beyond_4_gib(dev):
         assert np.array_equal(out["el"].cpu().numpy(), exp.elected)
         assert np.array_equal(out["st"].cpu().numpy(), exp.status)
         vt_out.zero_()
+
+
+def test_pinned_host_buffers(engine):
+    b = synth.gen_fused(30000, 5, seed=44)
+    pinned = [engine.pinned_like(a) for a in b.fused_args()]
+    got = engine.fused_round(*pinned)
+    exp = o.fused_round(*b.fused_args())
+    assert np.array_equal(got.commit, exp.commit)
+    assert_vote_equal(got, exp, b.G)

@@ -95,7 +95,15 @@ with QuorumEngine(max_groups=G, max_slots=n, max_log_terms=int(hb.log_term.size)
     for _ in range(3):
         qe.fused_round(*hb.fused_args())
     sec = (time.perf_counter() - t0) / 3
-out.append(rate("1M x 5 fused round through rq_fused_round (host buffers, PCIe inclusive)", G, 137, sec))
+out.append(rate("1M x 5 fused round through rq_fused_round (pageable host buffers, PCIe inclusive)", G, 137, sec))
+with QuorumEngine(max_groups=G, max_slots=n, max_log_terms=int(hb.log_term.size)) as qe:
+    pinned = [qe.pinned_like(a) for a in hb.fused_args()]
+    qe.fused_round(*pinned)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        qe.fused_round(*pinned)
+    sec = (time.perf_counter() - t0) / 3
+out.append(rate("same, inputs in rq_host_alloc (page-locked) memory; outputs pageable", G, 137, sec))
 del sets
 torch.cuda.empty_cache()
 
