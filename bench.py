@@ -59,6 +59,9 @@ def parse():
                     help="initialise torch.distributed and run the summary all-gather even with one rank")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--log-window", type=int, default=-1,
+                    help=">= 0: keep only the uncommitted suffix of every log plus this many committed "
+                         "entries on the device (log_base window); -1: full logs (the default workload)")
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
     ap.add_argument("--no-status", action="store_true", help="skip the per-group status byte output")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
@@ -136,6 +139,8 @@ def main():
         seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
         if args.workload == "fused":
             b = synth.gen_fused(G, n, seed=seed, ld=G + args.ld_pad)
+            if args.log_window >= 0:
+                b = synth.window_logs(b, keep_committed=args.log_window)
         else:                                # the 0.9 GB log arena is generated once and shared
             b = synth.gen_mixed(G, seed=seed, logs_from=first_mixed)
             first_mixed = first_mixed or b
@@ -231,7 +236,7 @@ def main():
                        "summary_mode": args.summary if ex is not None else None,
                        "summary_impl": ex.impl if ex is not None else None,
                        "rounds_per_allgather": R if ex is not None else None,
-                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad,
+                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "log_window": args.log_window,
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

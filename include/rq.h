@@ -232,6 +232,11 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  * the escape value 65535, in which case *summary_escapes (if not NULL) is
  * incremented and the receiver must fetch the full commit vector; the host
  * moves summary_base forward before offsets reach the window's end.
+ * log_base, if not NULL, makes the log arena a window: slot i of group g's
+ * arena slice holds log[log_base[g] + i], so a host may keep only the
+ * uncommitted suffix of every log on the device (entries at or below
+ * commitIndex can never be looked up: the rule needs N > commitIndex); an N
+ * below the base is reported as RQ_ST_LOG_OOB like an N past the end.
  * variant selects a kernel build:
  * 0 = library default; other values are tuning knobs listed in rq_kernels.h
  * and never change results. */
@@ -248,13 +253,13 @@ int rq_fused_round_dev(rq_engine *e, void *stream, int variant,
                        uint8_t *elected, int32_t *max_term,
                        uint8_t *status_out, uint64_t *elected_bits,
                        uint16_t *commit_lo16, const int32_t *summary_base,
-                       uint32_t *summary_escapes);
+                       uint32_t *summary_escapes, const int32_t *log_base);
 int rq_commit_advance_dev(rq_engine *e, void *stream, int variant,
                           uint32_t G, uint32_t n, uint32_t ld,
                           const int32_t *match, const int32_t *commit,
                           const int32_t *leader_term, const uint32_t *log_off,
                           const int32_t *log_term, int32_t *commit_out,
-                          uint8_t *status_out);
+                          uint8_t *status_out, const int32_t *log_base);
 int rq_vote_tally_dev(rq_engine *e, void *stream, int variant,
                       uint32_t G, uint32_t n, uint32_t ld,
                       const int32_t *voter_term, const int32_t *voted_for,
@@ -278,7 +283,7 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant,
                              uint8_t *elected, int32_t *max_term,
                              uint8_t *status_out, uint64_t *elected_bits,
                              uint16_t *commit_lo16, const int32_t *summary_base,
-                             uint32_t *summary_escapes);
+                             uint32_t *summary_escapes, const int32_t *log_base);
 /* Prepared launches.  rq_plan_fused_round validates one rq_fused_round_dev
  * argument set once (joint = 0) or one rq_fused_round_joint_dev set (joint = 1,
  * old_mask/new_mask then required, n = number of slot planes) and keeps it;
@@ -301,7 +306,7 @@ int rq_plan_fused_round(rq_engine *e, int variant, int joint,
                         uint8_t *elected, int32_t *max_term,
                         uint8_t *status_out, uint64_t *elected_bits,
                         uint16_t *commit_lo16, const int32_t *summary_base,
-                        uint32_t *summary_escapes, rq_plan **out);
+                        uint32_t *summary_escapes, const int32_t *log_base, rq_plan **out);
 int rq_plan_launch(rq_plan *p, void *stream);
 int rq_plan_destroy(rq_plan *p);
 

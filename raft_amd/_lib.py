@@ -46,11 +46,11 @@ PROTOTYPES = {
     "rq_step": [vp, u32],
     "rq_download": [vp, i32p] + _VOTE_OUT + [u8p],
     # device-pointer launches: raw addresses (void*) so torch data_ptr() ints pass through
-    "rq_fused_round_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 21,
-    "rq_commit_advance_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 7,
+    "rq_fused_round_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 22,
+    "rq_commit_advance_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 8,
     "rq_vote_tally_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 12,
-    "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 23,
-    "rq_plan_fused_round": [vp, cint, cint, u32, u32, u32] + [vp] * 23 + [C.POINTER(vp)],
+    "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 24,
+    "rq_plan_fused_round": [vp, cint, cint, u32, u32, u32] + [vp] * 24 + [C.POINTER(vp)],
     "rq_plan_launch": [vp, vp],
     "rq_plan_destroy": [vp],
     "rq_stream_sync": [vp, vp],

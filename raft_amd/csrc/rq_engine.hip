@@ -640,7 +640,7 @@ int rq_fused_round_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint
                        uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
                        int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
                        uint16_t *commit_lo16, const int32_t *summary_base,
-                       uint32_t *summary_escapes) {
+                       uint32_t *summary_escapes, const int32_t *log_base) {
     rq_round_args a;
     std::memset(&a, 0, sizeof a);
     a.G = G; a.ld = ld; a.m = n;
@@ -652,19 +652,21 @@ int rq_fused_round_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint
     a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
     a.status_out = status_out; a.elected_bits = elected_bits;
     a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
+    a.log_base = log_base;
     return dev_launch(e, stream, variant, n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
 }
 
 int rq_commit_advance_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n,
                           uint32_t ld, const int32_t *match, const int32_t *commit,
                           const int32_t *leader_term, const uint32_t *log_off,
-                          const int32_t *log_term, int32_t *commit_out, uint8_t *status_out) {
+                          const int32_t *log_term, int32_t *commit_out, uint8_t *status_out,
+                          const int32_t *log_base) {
     rq_round_args a;
     std::memset(&a, 0, sizeof a);
     a.G = G; a.ld = ld; a.m = n;
     a.match = match; a.commit = commit; a.leader_term = leader_term;
     a.log_off = log_off; a.log_term = log_term;
-    a.commit_out = commit_out; a.status_out = status_out;
+    a.commit_out = commit_out; a.status_out = status_out; a.log_base = log_base;
     return dev_launch(e, stream, variant, n, false, RQ_WHAT_COMMIT, a);
 }
 
@@ -696,7 +698,7 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G
                              uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
                              uint8_t *status_out, uint64_t *elected_bits,
                              uint16_t *commit_lo16, const int32_t *summary_base,
-                             uint32_t *summary_escapes) {
+                             uint32_t *summary_escapes, const int32_t *log_base) {
     rq_round_args a;
     std::memset(&a, 0, sizeof a);
     a.G = G; a.ld = ld; a.m = m;
@@ -709,6 +711,7 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G
     a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
     a.status_out = status_out; a.elected_bits = elected_bits;
     a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
+    a.log_base = log_base;
     return dev_launch(e, stream, variant, m, true, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
 }
 
@@ -773,7 +776,7 @@ int rq_plan_fused_round(rq_engine *e, int variant, int joint, uint32_t G, uint32
                         uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
                         int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
                         uint16_t *commit_lo16, const int32_t *summary_base,
-                        uint32_t *summary_escapes, rq_plan **out) {
+                        uint32_t *summary_escapes, const int32_t *log_base, rq_plan **out) {
     if (!e || !out) return RQ_E_ARG;
     *out = nullptr;
     rq_round_args a;
@@ -788,6 +791,7 @@ int rq_plan_fused_round(rq_engine *e, int variant, int joint, uint32_t G, uint32
     a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
     a.status_out = status_out; a.elected_bits = elected_bits;
     a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
+    a.log_base = log_base;
     if (n < 1 || n > RQ_MAX_SLOTS || ld < G || G > 0x7FFFFFFFu) return RQ_E_ARG;
     if (!match || !commit || !leader_term || !log_off || !log_term || !commit_out || !voter_term ||
         !voted_for || !voter_last_log_term || !cand_term || !cand_id || !voter_term_out ||

@@ -16,6 +16,7 @@ struct rq_round_args {
     const int32_t  *leader_term;
     const uint32_t *log_off;
     const int32_t  *log_term;
+    const int32_t  *log_base;    // may be null (0): arena slot 0 of group g holds log[log_base[g]]
     // vote side (RequestVoteRPC inputs, raft.go:181-210)
     const int32_t  *voter_term;
     const int32_t  *voted_for;

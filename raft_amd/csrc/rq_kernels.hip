@@ -263,7 +263,9 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
     constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
     const size_t ld = a.ld;
 
-    int32_t mt[N][V], cm[V], lt[V], off[V + 1];
+    int32_t mt[N][V], cm[V], lt[V], off[V + 1], lb[V];
+#pragma unroll
+    for (int k = 0; k < V; k++) lb[k] = 0;
     int32_t vt[N][V], vf[N][V], ll[N][V], ct[V], ci[V];
     uint32_t st[V];
 #pragma unroll
@@ -275,6 +277,7 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
         for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
         ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
         ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
+        if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
         const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
         int32_t o[V];
         ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -307,14 +310,17 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
             for (int p = 0; p < N; p++) s[p] = mt[p][k];
             nq[k] = quorum_index<N>(s);
             const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
+            // window: arena slot i of the group holds log[base + i]; N below the base wraps
+            // to a huge unsigned value and is reported like any other N outside the arena
+            const uint32_t wi = (uint32_t)nq[k] - (uint32_t)lb[k];
             adv[k] = (k < valid) && nq[k] > cm[k];
-            inb[k] = (uint32_t)nq[k] < len;
+            inb[k] = wi < len;
             gt[k] = 0;
             if (adv[k] && inb[k]) {
                 if ((FLAGS & RQ_VAR_LDS_LOG) && lds_log)   // the block's arena segment is in LDS
-                    gt[k] = lds_log[(uint32_t)off[k] - lds_seg0 + (uint32_t)nq[k]];
+                    gt[k] = lds_log[(uint32_t)off[k] - lds_seg0 + wi];
                 else
-                    gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]));
+                    gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + wi));
             }
         }
     }
@@ -564,12 +570,14 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
                 if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
             }
         }
+        int32_t lb[V];
 #pragma unroll
-        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; }
+        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; }
         off[V] = 0;
         if (in_range) {
             ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
             ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
+            if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
             const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
             int32_t o[V];
             ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -596,10 +604,11 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
             }
             nq[k] = min(no, nn);
             const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
+            const uint32_t wi = (uint32_t)nq[k] - (uint32_t)lb[k];
             adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
-            inb[k] = (uint32_t)nq[k] < len;
+            inb[k] = wi < len;
             gt[k] = 0;
-            if (adv[k] && inb[k]) gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + (uint32_t)nq[k]));
+            if (adv[k] && inb[k]) gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + wi));
         }
     }
 
@@ -860,7 +869,7 @@ int pick_v(const rq_round_args &a, int want, int what) {
         bool ok = (a.ld % v) == 0;
         if (what & RQ_WHAT_COMMIT)
             ok = ok && aligned_to(a.commit_lo16, 2 * v) && aligned_to(a.match, 4 * v) && aligned_to(a.commit, 4 * v) &&
-                 aligned_to(a.leader_term, 4 * v) && aligned_to(a.log_off, 4 * v) &&
+                 aligned_to(a.leader_term, 4 * v) && aligned_to(a.log_off, 4 * v) && aligned_to(a.log_base, 4 * v) &&
                  aligned_to(a.commit_out, 4 * v);
         if (what & RQ_WHAT_VOTE)
             ok = ok && aligned_to(a.voter_term, 4 * v) && aligned_to(a.voted_for, 4 * v) &&

@@ -46,6 +46,8 @@ class DeviceBatch:
             if a.size == 0:
                 a = np.zeros(1, a.dtype)
             host[k] = np.ascontiguousarray(a)
+        if "log_base" in batch:                 # windowed log arena
+            host["log_base"] = np.ascontiguousarray(batch["log_base"], dtype=np.int32)
         if self.joint:
             host["old_mask"] = np.ascontiguousarray(batch["old_mask"].view(np.int16))
             host["new_mask"] = np.ascontiguousarray(batch["new_mask"].view(np.int16))
@@ -170,7 +172,8 @@ class DeviceEngine:
                 p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
                 p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
                 p(o["elected_bits"]) if want_bits else None,
-                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]), C.byref(plan))
+                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]), p(t.get("log_base")),
+                C.byref(plan))
             if rc != 0:
                 self._check(rc, "rq_plan_fused_round")
             b._args[key] = plan
@@ -189,7 +192,7 @@ class DeviceEngine:
                 p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
                 p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
                 p(o["elected_bits"]) if want_bits else None,
-                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"])]
+                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]), p(t.get("log_base"))]
         if b.joint:
             rc = self._l.rq_fused_round_joint_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
                                                   p(t["old_mask"]), p(t["new_mask"]), *tail)
@@ -204,7 +207,8 @@ class DeviceEngine:
         rc = self._l.rq_commit_advance_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
                                            p(t["match"]), p(t["commit"]), p(t["leader_term"]),
                                            p(t["log_off"]), p(t["log_term"]), p(o["commit_out"]),
-                                           p(o["status"]))
+                                           p(o["status"]),
+                                           t["log_base"].data_ptr() if "log_base" in t else None)
         self._check(rc, "rq_commit_advance_dev")
 
     def vote_tally(self, b, variant=VAR_DEFAULT, want_bits=True):

@@ -291,3 +291,22 @@ def gen_append(G, n, seed=DEFAULT_SEED, ld=None, max_len=12, adversarial=False):
                  n_new=nn.astype(np.int32).reshape(shape), flog_off=off, flog_term=flog,
                  match_index=mi.astype(np.int32).reshape(shape), next_index=ni.astype(np.int32).reshape(shape),
                  active_mask=act.astype(np.uint16))
+
+
+def window_logs(b, keep_committed=0):
+    """A copy of batch b whose log arena holds, for every group, only the entries
+    above commitIndex - keep_committed (the uncommitted suffix plus a few entries
+    a lazy compaction has not dropped yet); adds log_base.  Decisions are
+    unchanged: the commit rule only ever reads log[N] with N > commitIndex."""
+    G = int(b["G"])
+    off = b["log_off"].astype(np.int64)
+    lens = np.diff(off)
+    base = np.clip(b["commit"][:G].astype(np.int64) + 1 - keep_committed, 0, lens)
+    new_lens = lens - base
+    new_off = _csr(new_lens)
+    grp = np.repeat(np.arange(G, dtype=np.int64), new_lens)
+    pos = np.arange(int(new_off[-1]), dtype=np.int64) - new_off[:-1].astype(np.int64)[grp]
+    arena = b["log_term"][off[:-1][grp] + base[grp] + pos] if grp.size else np.zeros(0, np.int32)
+    w = Batch(b)
+    w["log_off"], w["log_term"], w["log_base"] = new_off, arena.astype(np.int32), base.astype(np.int32)
+    return w

@@ -96,7 +96,20 @@ class Result(dict):
     __getattr__ = dict.__getitem__
 
 
-def commit_advance(match, commit, leader_term, log_off, log_term, G=None, old_mask=None, new_mask=None):
+def commit_advance(match, commit, leader_term, log_off, log_term, G=None, old_mask=None, new_mask=None,
+                   log_base=None):
+    """log_base: the arena is a window (slot i of a group holds log[base + i]).  The
+    reference-shaped leader is then evaluated in the window's own coordinates:
+    matchIndex and commitIndex shifted down by base (the quorum index and the
+    N > commitIndex test are shift-invariant), the result shifted back."""
+    if log_base is not None:
+        base = _c(log_base, np.int32).astype(np.int64)
+        m64 = _c(match, np.int32).astype(np.int64) - base[None, :]
+        c64 = _c(commit, np.int32).astype(np.int64) - base
+        assert np.abs(m64).max(initial=0) < 2 ** 31 and np.abs(c64).max(initial=0) < 2 ** 31
+        out, st = commit_advance(m64.astype(np.int32), c64.astype(np.int32), leader_term, log_off, log_term,
+                                 G, old_mask, new_mask)
+        return (out.astype(np.int64) + base[: out.size]).astype(np.int32), st
     match = _c(match, np.int32); n, ld = match.shape; G = ld if G is None else G
     commit = _c(commit, np.int32); leader_term = _c(leader_term, np.int32)
     log_off = _c(log_off, np.uint32); log_term = _c(log_term, np.int32)
@@ -133,9 +146,9 @@ def vote_tally(voter_term, voted_for, last_log_term, cand_term, cand_id, G=None,
 
 
 def fused_round(match, commit, leader_term, log_off, log_term, voter_term, voted_for, last_log_term,
-                cand_term, cand_id, G=None, old_mask=None, new_mask=None):
+                cand_term, cand_id, G=None, old_mask=None, new_mask=None, log_base=None):
     """The oracle has no fused form: a fused round IS the two decisions side by side."""
-    c, st_c = commit_advance(match, commit, leader_term, log_off, log_term, G, old_mask, new_mask)
+    c, st_c = commit_advance(match, commit, leader_term, log_off, log_term, G, old_mask, new_mask, log_base)
     r = vote_tally(voter_term, voted_for, last_log_term, cand_term, cand_id, G, old_mask, new_mask)
     r["commit"] = c
     r["status"] = r["status"] | st_c

@@ -394,7 +394,7 @@ def test_device_memory_helpers_round_trip(dev):
     back = np.zeros_like(b.match)
     dev.download(addrs[0], back)
     assert np.array_equal(back, b.match)
-    rc = dev._l.rq_commit_advance_dev(dev._h, None, 0, b.G, b.n, b.ld, *addrs)
+    rc = dev._l.rq_commit_advance_dev(dev._h, None, 0, b.G, b.n, b.ld, *addrs, None)
     assert rc == 0
     assert dev._l.rq_stream_sync(dev._h, None) == 0
     c = np.zeros(b.G, np.int32); st = np.zeros(b.G, np.uint8)
@@ -505,7 +505,7 @@ def test_plane_offsets_beyond_4_gib(dev):
                                        p(vec["log_term"]), p(planes["voter_term"]), p(planes["voted_for"]),
                                        p(planes["last_log_term"]), p(vec["cand_term"]), p(vec["cand_id"]),
                                        p(out["commit"]), p(vt_out), p(out["grant"]), p(out["sd"]), p(out["el"]),
-                                       p(out["mx"]), p(out["st"]), None, None, None, None)
+                                       p(out["mx"]), p(out["st"]), None, None, None, None, None)
         assert rc == 0
         torch.cuda.synchronize()
         assert np.array_equal(out["commit"].cpu().numpy(), exp.commit)
@@ -523,3 +523,37 @@ def test_pinned_host_buffers(engine):
     exp = o.fused_round(*b.fused_args())
     assert np.array_equal(got.commit, exp.commit)
     assert_vote_equal(got, exp, b.G)
+
+
+@pytest.mark.parametrize("variant", [0, 0x234, 0x1b1])
+def test_windowed_log_arena(dev, variant):
+    """log_base: the arena holds only a suffix of every log.  Same decisions as
+    with the full logs whenever the window still covers N; N below the base is a
+    status bit.  Fixed and joint kernels, fused and commit-only."""
+    from raft_amd.device import DeviceBatch
+    for joint in (False, True):
+        G = 40000
+        full = synth.gen_mixed(G, seed=11) if joint else synth.gen_fused(G, 5, seed=11)
+        kw = dict(old_mask=full.old_mask, new_mask=full.new_mask) if joint else {}
+        exp_full = o.fused_round(*full.fused_args(), **kw)
+        w = synth.window_logs(full, keep_committed=1)
+        assert w.log_term.size < full.log_term.size
+        exp = o.fused_round(*w.fused_args(), log_base=w.log_base, **kw)
+        assert np.array_equal(exp.commit, exp_full.commit) and np.array_equal(exp.status, exp_full.status)
+        db = DeviceBatch(w)
+        dev.fused_round(db, variant=variant)
+        res = db.results()
+        assert np.array_equal(res["commit"], exp.commit) and np.array_equal(res["status"], exp.status)
+        # a base beyond some groups' N: those groups report the window miss and do not advance
+        w2 = synth.Batch(w)
+        w2["log_base"] = (w.log_base + (np.arange(G) % 3 == 0) * 3).astype(np.int32)
+        exp2 = o.fused_round(*w2.fused_args(), log_base=w2.log_base, **kw)
+        assert (exp2.status & 1).any()
+        db2 = DeviceBatch(w2)
+        dev.fused_round(db2, variant=variant)
+        res2 = db2.results()
+        assert np.array_equal(res2["commit"], exp2.commit) and np.array_equal(res2["status"], exp2.status)
+        if not joint:
+            db3 = DeviceBatch(w2)
+            dev.commit_advance(db3)
+            assert np.array_equal(db3.results()["commit"], exp2.commit)
