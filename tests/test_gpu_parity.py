@@ -557,3 +557,47 @@ def test_windowed_log_arena(dev, variant):
             db3 = DeviceBatch(w2)
             dev.commit_advance(db3)
             assert np.array_equal(db3.results()["commit"], exp2.commit)
+
+
+def test_fuzz_shapes_and_variants(dev):
+    """Random group counts, cluster sizes, plane strides and kernel builds."""
+    from raft_amd.device import DeviceBatch
+    rng = np.random.default_rng(2024)
+    variants = [0, 1, 2, 4, 0x31, 0x32, 0x34, 0x71, 0x131, 0x171, 0x271, 0x274, 0x2b1, 0x371, 0x472]
+    for it in range(60):
+        n = int(rng.integers(1, 17))
+        G = int(rng.integers(1, 3000))
+        ld = G + int(rng.choice([0, 1, 3, 4, 64, 129]))
+        variant = int(rng.choice(variants))
+        gen = synth.gen_adversarial if it % 2 else synth.gen_fused
+        b = gen(G, n, seed=5000 + it, ld=ld)
+        exp = o.fused_round(*b.fused_args(), G=G)
+        db = DeviceBatch(b)
+        dev.fused_round(db, variant=variant)
+        _check_dev(db.results(), exp, G)
+
+
+def test_two_engines_from_two_threads():
+    """Distinct engines may be driven concurrently (one stream and one mutex each)."""
+    import threading
+    from raft_amd import QuorumEngine
+    errs = []
+
+    def worker(seed):
+        try:
+            b = synth.gen_adversarial(20000, 5, seed=seed)
+            exp = o.fused_round(*b.fused_args())
+            with QuorumEngine(max_groups=b.G, max_slots=5, max_log_terms=int(b.log_term.size) + 8) as e:
+                for _ in range(20):
+                    got = e.fused_round(*b.fused_args())
+                    assert np.array_equal(got.commit, exp.commit)
+                    assert np.array_equal(got.grant_mask, exp.grant_mask)
+        except Exception as ex:  # noqa: BLE001
+            errs.append(repr(ex))
+
+    ts = [threading.Thread(target=worker, args=(s,)) for s in (1, 2, 3)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
