@@ -601,3 +601,49 @@ def test_two_engines_from_two_threads():
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_sharded_exchange_one_rank_on_gpu(dev):
+    """The sharded path end to end with the ranks that exist here (one): the
+    kernel writes its 16-bit commit summary and elected bits straight into a
+    SummaryExchange slot, the slot is all-gathered over RCCL (torch.distributed
+    and librq's own communicator), and the gathered vectors equal the oracle's."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from raft_amd.device import DeviceBatch
+    from raft_amd.sharded import SummaryExchange
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    device = torch.device("cuda:0")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=device)
+    try:
+        G, R = 30011, 2
+        for impl in ("torch", "native"):
+            ex = SummaryExchange(G, device, depth=2, mode="u16", impl=impl, rounds=R)
+            assert ex.impl == impl
+            esc = torch.zeros(2, dtype=torch.int32, device=device)
+            exps, batches = [], []
+            for i in range(2 * R):
+                slot, sub = i // R, i % R
+                b = synth.gen_fused(G, 5, seed=60 + i)
+                exps.append(o.fused_round(*b.fused_args()))
+                db = DeviceBatch(b, commit_lo16=ex.commit_view(slot, sub), elected_bits=ex.bits_view(slot, sub),
+                                 summary_escapes=esc)
+                batches.append(db)
+                if sub == 0:
+                    ex.begin(slot)
+                dev.fused_round(db)
+                if sub == R - 1:
+                    ex.exchange(slot)
+            ex.wait_all()
+            torch.cuda.synchronize()
+            for i in range(2 * R):
+                slot, sub = i // R, i % R
+                assert np.array_equal(ex.gathered_commit(slot, sub).cpu().numpy().reshape(-1), exps[i].commit)
+                bits = ex.gathered_bits(slot, sub).cpu().numpy().view(np.uint8)
+                assert np.array_equal(np.unpackbits(bits, bitorder="little")[:G], exps[i].elected)
+            assert int(esc[0]) == 0
+            ex.close()
+    finally:
+        dist.destroy_process_group()
