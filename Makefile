@@ -8,11 +8,11 @@ CSRC     = raft_amd/csrc
 
 all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h include/rq.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h include/rq.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-raft_amd/librq.so: build/rq_kernels.o build/rq_engine.o build/rq_comm.o
+raft_amd/librq.so: build/rq_kernels.o build/rq_kernels64.o build/rq_engine.o build/rq_comm.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -ldl -o $@
 
 HOST = $(CSRC)/host

@@ -27,10 +27,12 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak
 
 
-def alg_bytes_per_group(n, what="fused"):
-    """Algorithmic bytes per group-round, int32 layout: commit 4n+20, vote 16n+17."""
-    commit = 4 * n + 20      # n match + commit + leaderTerm + logOff + gathered term ; commit'
-    vote = 16 * n + 17       # 3n planes + candTerm + candId ; n voterTerm' + 2 + 2 + 1 + 4
+def alg_bytes_per_group(n, what="fused", layout="i32"):
+    """Algorithmic bytes per group-round.  int32 layout: commit 4n+20, vote 16n+17;
+    int64 layout (every value 8 bytes, log offsets still 4): commit 8n+36, vote 32n+29."""
+    e = 8 if layout == "i64" else 4
+    commit = e * n + 3 * e + 4 + e   # n match + commit + leaderTerm + gathered term + logOff ; commit'
+    vote = 4 * e * n + 3 * e + 5     # 3n planes + candTerm + candId ; n voterTerm' + maxTerm + 2 + 2 + 1
     return {"commit": commit, "vote": vote, "fused": commit + vote}[what]
 
 
@@ -62,6 +64,8 @@ def parse():
     ap.add_argument("--log-window", type=int, default=-1,
                     help=">= 0: keep only the uncommitted suffix of every log plus this many committed "
                          "entries on the device (log_base window); -1: full logs (the default workload)")
+    ap.add_argument("--layout", choices=["i32", "i64"], default="i32",
+                    help="i64: the wide layout (rq_round64_dev), values shifted beyond the int32 range")
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
     ap.add_argument("--no-status", action="store_true", help="skip the per-group status byte output")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
@@ -144,6 +148,12 @@ def main():
         else:                                # the 0.9 GB log arena is generated once and shared
             b = synth.gen_mixed(G, seed=seed, logs_from=first_mixed)
             first_mixed = first_mixed or b
+        if args.layout == "i64":
+            if args.workload == "mixed" or (ex is not None and args.summary == "i32"):
+                raise SystemExit("--layout i64 runs the fused workload with the u16 summary")
+            # indices can only leave the int32 range together with a window base
+            b, _ = synth.widen(b, index_shift=(1 << 40) if args.log_window >= 0 else 0,
+                               term_shift=1 << 41, id_shift=1 << 42, seed=seed)
         kw = {}
         if args.workload == "mixed" and sets:
             kw["share_log_with"] = sets[0]
@@ -154,7 +164,7 @@ def main():
                       summary_escapes=escape_counter)
         sets.append(DeviceBatch(b, device, **kw))
     if args.workload == "fused":
-        bytes_per_group = alg_bytes_per_group(n, args.what)
+        bytes_per_group = alg_bytes_per_group(n, args.what, args.layout)
         workload = "%d groups x %d peers per GPU, fused RequestVote tally + commitIndex advance with log-term gather" % (G, n)
     else:
         om = b.old_mask.astype("int64"); nm = b.new_mask.astype("int64")
@@ -219,7 +229,7 @@ def main():
         traffic = None
         try:
             tj = json.load(open(args.traffic_json))
-            key = "%s_G%d_n%d" % (args.workload, G, n)
+            key = "%s%s_G%d_n%d" % (args.workload, "_i64" if args.layout == "i64" else "", G, n)
             traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
         except (OSError, ValueError):
             pass
@@ -228,7 +238,7 @@ def main():
             "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int32", "data": "synthetic",
+            "dtype": "int64" if args.layout == "i64" else "int32", "data": "synthetic",
             "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
                        "resident_mb_per_gpu": round(resident_mb, 1),
                        "summary_allgather": bool(exchange),
@@ -236,7 +246,7 @@ def main():
                        "summary_mode": args.summary if ex is not None else None,
                        "summary_impl": ex.impl if ex is not None else None,
                        "rounds_per_allgather": R if ex is not None else None,
-                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "log_window": args.log_window,
+                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "log_window": args.log_window, "layout": args.layout,
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

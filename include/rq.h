@@ -10,8 +10,9 @@
  *     field[p * ld + g]      p = slot (peer) 0..n-1,  g = group 0..G-1
  * with ld >= G the plane stride in elements.  n counts every member of the
  * cluster INCLUDING the node itself (raft.go:94-97, :114).  Terms, indices
- * and ids are int32 (Go int is 64-bit: the host narrows and rejects values
- * outside int32).  Leader logs are a CSR arena: group g's log is
+ * and ids are int32 in the compact layout (Go int is 64-bit: the host narrows
+ * and rejects values outside int32) and int64 in the wide layout of the
+ * rq_round64* entry points.  Leader logs are a CSR arena: group g's log is
  *     log_term[log_off[g] .. log_off[g+1])      slot i holds log[i].TermNum
  * indexed directly by slot (the convention of raft.go:151).
  *
@@ -320,6 +321,52 @@ int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint
                         uint16_t *stepdown_mask, int32_t *match_index_io,
                         int32_t *next_index_io, uint8_t *status_out);
 int rq_stream_sync(rq_engine *e, void *stream);
+
+/* ---- wide layout: 64-bit terms, indices and ids -------------------------- *
+ * The same round over int64_t planes, for hosts whose values do not fit the
+ * compact layout (Go's int is 64-bit on amd64, raft.go:35-68).  Same rules,
+ * same status bits, same masks and byte outputs; an empty voter log is
+ * RQ_LOG_EMPTY64.  `what` selects the decisions: RQ_ROUND_COMMIT, RQ_ROUND_VOTE
+ * or both (one launch either way); the pointers of the side that is not
+ * selected may be NULL.  m slot planes; old_mask/new_mask are either both NULL
+ * (every group has the m slots as its one configuration: the fixed-size round)
+ * or both given (the joint-consensus round described above).  log_base may be
+ * NULL (see the device-pointer section for its meaning); log_off stays 32-bit
+ * (it indexes the arena, it is not a Raft value).
+ * rq_round64 works on host buffers like rq_fused_round (its 64-bit staging
+ * buffers are allocated by the first call and kept); rq_round64_dev enqueues a
+ * launch on device buffers like rq_fused_round_joint_dev, with the same
+ * variant word (one group per thread in this layout), elected_bits and narrow
+ * commit summary. */
+#define RQ_LOG_EMPTY64  INT64_MIN
+#define RQ_ROUND_COMMIT 1
+#define RQ_ROUND_VOTE   2
+int rq_round64(rq_engine *e, int what, uint32_t G, uint32_t m, uint32_t ld,
+               const uint16_t *old_mask, const uint16_t *new_mask,
+               const int64_t *match, const int64_t *commit,
+               const int64_t *leader_term, const uint32_t *log_off,
+               const int64_t *log_term, const int64_t *log_base,
+               const int64_t *voter_term, const int64_t *voted_for,
+               const int64_t *voter_last_log_term,
+               const int64_t *cand_term, const int64_t *cand_id,
+               int64_t *commit_out, int64_t *voter_term_out,
+               uint16_t *grant_mask, uint16_t *stepdown_mask,
+               uint8_t *elected, int64_t *max_term, uint8_t *status_out);
+int rq_round64_dev(rq_engine *e, void *stream, int variant, int what,
+                   uint32_t G, uint32_t m, uint32_t ld,
+                   const uint16_t *old_mask, const uint16_t *new_mask,
+                   const int64_t *match, const int64_t *commit,
+                   const int64_t *leader_term, const uint32_t *log_off,
+                   const int64_t *log_term, const int64_t *log_base,
+                   const int64_t *voter_term, const int64_t *voted_for,
+                   const int64_t *voter_last_log_term,
+                   const int64_t *cand_term, const int64_t *cand_id,
+                   int64_t *commit_out, int64_t *voter_term_out,
+                   uint16_t *grant_mask, uint16_t *stepdown_mask,
+                   uint8_t *elected, int64_t *max_term,
+                   uint8_t *status_out, uint64_t *elected_bits,
+                   uint16_t *commit_lo16, const int64_t *summary_base,
+                   uint32_t *summary_escapes);
 
 /* Device memory for hosts that keep group state resident without another GPU
  * runtime binding (a Go host has none), to be used with the *_dev launches.

@@ -419,6 +419,91 @@ int orc_vote_tally_joint(uint32_t G, uint32_t m, uint32_t ld,
     return 0;
 }
 
+/* ---- wide layout: the same decisions over int64 planes ------------------- */
+
+/* Leader rule with a windowed log: window slot i holds log[base + i].  The
+ * reference-shaped leader is evaluated in the window's own coordinates, as a
+ * one-slot cluster whose matchIndex is N - base and whose commitIndex is just
+ * below it (N > commitIndex is decided here, on the unshifted values, so no
+ * shifted quantity can overflow). */
+static int64_t commit_one64(int64_t N, int64_t commit, int64_t leader_term,
+                            const int64_t *lt, int64_t len, int64_t base,
+                            uint8_t *status) {
+    if (!(N > commit)) return commit;
+    uint64_t wi = (uint64_t)N - (uint64_t)base;
+    if (N < base || wi >= (uint64_t)len) { *status |= ORC_ST_LOG_OOB; return commit; }
+    rf_entry ent; ent.command = ""; ent.index = N; ent.term_num = lt[wi];
+    int64_t one = 0;
+    rf_node L; memset(&L, 0, sizeof L);
+    L.node_type = RF_LEADER; L.n_peers = 1; L.current_term = leader_term;
+    L.commit_index = -1; L.log = &ent; L.log_len = 1; L.match_index = &one;
+    if (rf_leader_advance_commit(&L) != RF_OK) { *status |= ORC_ST_LOG_OOB; return commit; }
+    return L.commit_index == 0 ? N : commit;
+}
+
+int orc_round64(int what, uint32_t G, uint32_t m, uint32_t ld,
+                const uint16_t *old_mask, const uint16_t *new_mask,
+                const int64_t *match, const int64_t *commit,
+                const int64_t *leader_term, const uint32_t *log_off,
+                const int64_t *log_term, const int64_t *log_base,
+                const int64_t *voter_term, const int64_t *voted_for,
+                const int64_t *voter_last_log_term,
+                const int64_t *cand_term, const int64_t *cand_id,
+                int64_t *commit_out, int64_t *voter_term_out,
+                uint16_t *grant_mask, uint16_t *stepdown_mask,
+                uint8_t *elected, int64_t *max_term, uint8_t *status_out) {
+    if (m < 1 || m > ORC_MAX_SLOTS || ld < G) return -1;
+    if ((old_mask == NULL) != (new_mask == NULL)) return -1;
+    uint32_t lim = m >= 16 ? 0xFFFFu : ((1u << m) - 1u);
+    for (uint32_t g = 0; g < G; g++) {
+        uint32_t om = old_mask ? (old_mask[g] & lim) : lim;
+        uint32_t nm = new_mask ? (new_mask[g] & lim) : lim;
+        if (!om || !nm) return -2;
+        uint32_t mem = om | nm;
+        uint8_t st = 0;
+        if (what & 1) {
+            int64_t mt[ORC_MAX_SLOTS];
+            for (uint32_t p = 0; p < m; p++)
+                mt[p] = (mem >> p & 1) ? match[(size_t)p * ld + g] : 0;
+            int64_t N = rf_min_int(subset_quorum(mt, m, om), subset_quorum(mt, m, nm));
+            commit_out[g] = commit_one64(N, commit[g], leader_term[g], log_term + log_off[g],
+                                         (int64_t)log_off[g + 1] - (int64_t)log_off[g],
+                                         log_base ? log_base[g] : 0, &st);
+        }
+        if (what & 2) {
+            uint32_t gm = 0, sm = 0, pm = 0;
+            int64_t mx = INT64_MIN;
+            for (uint32_t p = 0; p < m; p++) {
+                if (!(mem >> p & 1)) continue;
+                size_t i = (size_t)p * ld + g;
+                rf_node v; rf_entry e;
+                memset(&v, 0, sizeof v);
+                v.node_type = RF_CANDIDATE;
+                v.current_term = voter_term[i];
+                v.voted_for = voted_for[i];
+                if (voter_last_log_term[i] != INT64_MIN) {
+                    e.command = ""; e.index = 0; e.term_num = voter_last_log_term[i];
+                    v.log = &e; v.log_len = 1;
+                }
+                int64_t before = v.current_term, tr; int granted;
+                if (rf_request_vote_rpc(&v, cand_term[g], cand_id[g], 0, 0, &tr, &granted) != RF_OK)
+                    pm |= 1u << p;
+                if (cand_term[g] > before) sm |= 1u << p;
+                if (granted) gm |= 1u << p;
+                if (tr > mx) mx = tr;
+                voter_term_out[i] = v.current_term;
+            }
+            int el = 2 * popcount16(gm & om) > popcount16(om) &&
+                     2 * popcount16(gm & nm) > popcount16(nm) && mx == cand_term[g];
+            grant_mask[g] = (uint16_t)gm; stepdown_mask[g] = (uint16_t)sm;
+            elected[g] = (uint8_t)el; max_term[g] = mx;
+            if (pm) st |= ORC_ST_EMPTY_LOG;
+        }
+        if (status_out) status_out[g] = st;
+    }
+    return 0;
+}
+
 /* raft.go:172-176 with minInt :226-231; may lower commitIndex when the last
  * new entry's index is below it, as the reference does. */
 int orc_follower_clamp(uint64_t count, const int32_t *leader_commit,

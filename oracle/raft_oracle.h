@@ -120,6 +120,21 @@ int orc_vote_tally_joint(uint32_t G, uint32_t m, uint32_t ld,
                          int32_t *voter_term_out, uint16_t *grant_mask,
                          uint16_t *stepdown_mask, uint8_t *elected,
                          int32_t *max_term, uint8_t *status_out);
+/* Wide layout: one call = commit (what & 1) and/or vote (what & 2) over int64
+ * planes; masks both NULL = every group has the m slots as one configuration;
+ * log_base NULL = 0 (window slot i of a group holds log[log_base + i]); an
+ * empty voter log is INT64_MIN. */
+int orc_round64(int what, uint32_t G, uint32_t m, uint32_t ld,
+                const uint16_t *old_mask, const uint16_t *new_mask,
+                const int64_t *match, const int64_t *commit,
+                const int64_t *leader_term, const uint32_t *log_off,
+                const int64_t *log_term, const int64_t *log_base,
+                const int64_t *voter_term, const int64_t *voted_for,
+                const int64_t *voter_last_log_term,
+                const int64_t *cand_term, const int64_t *cand_id,
+                int64_t *commit_out, int64_t *voter_term_out,
+                uint16_t *grant_mask, uint16_t *stepdown_mask,
+                uint8_t *elected, int64_t *max_term, uint8_t *status_out);
 int orc_follower_clamp(uint64_t count, const int32_t *leader_commit,
                        const int32_t *commit, const int32_t *last_new_index,
                        int32_t *commit_out);             /* raft.go:172-176 */

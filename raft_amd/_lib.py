@@ -50,6 +50,9 @@ PROTOTYPES = {
     "rq_commit_advance_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 8,
     "rq_vote_tally_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 12,
     "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 24,
+    # wide layout: what, G, m, ld, then 2 masks + 11 inputs + 7 outputs (host) / + 4 summary (device)
+    "rq_round64": [vp, cint, u32, u32, u32] + [vp] * 20,
+    "rq_round64_dev": [vp, vp, cint, cint, u32, u32, u32] + [vp] * 24,
     "rq_plan_fused_round": [vp, cint, cint, u32, u32, u32] + [vp] * 24 + [C.POINTER(vp)],
     "rq_plan_launch": [vp, vp],
     "rq_plan_destroy": [vp],

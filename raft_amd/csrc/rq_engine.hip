@@ -25,6 +25,7 @@ struct rq_engine {
     std::mutex mu;
     std::atomic<int> last_hip{0};
     char *slab = nullptr;
+    char *slab64 = nullptr;   // staging of the 64-bit host-buffer entry points (made on first use)
     // planes [max_slots][ld]
     int32_t *match = nullptr, *voter_term = nullptr, *voted_for = nullptr, *last_log_term = nullptr;
     // per group [ld]
@@ -68,16 +69,18 @@ int check_shape(const rq_engine *e, uint32_t G, uint32_t n, uint32_t ld) {
 }
 
 // copy n planes of G elements, host stride ld -> device stride e->ld
-int h2d_planes(rq_engine *e, int32_t *dst, const int32_t *src, uint32_t G, uint32_t n, uint32_t ld) {
+template <typename T>
+int h2d_planes(rq_engine *e, T *dst, const T *src, uint32_t G, uint32_t n, uint32_t ld) {
     if (G == 0) return RQ_OK;
-    RQ_HIP(e, hipMemcpy2DAsync(dst, (size_t)e->ld * 4, src, (size_t)ld * 4, (size_t)G * 4, n,
-                               hipMemcpyHostToDevice, e->stream));
+    RQ_HIP(e, hipMemcpy2DAsync(dst, (size_t)e->ld * sizeof(T), src, (size_t)ld * sizeof(T),
+                               (size_t)G * sizeof(T), n, hipMemcpyHostToDevice, e->stream));
     return RQ_OK;
 }
-int d2h_planes(rq_engine *e, int32_t *dst, const int32_t *src, uint32_t G, uint32_t n, uint32_t ld) {
+template <typename T>
+int d2h_planes(rq_engine *e, T *dst, const T *src, uint32_t G, uint32_t n, uint32_t ld) {
     if (G == 0) return RQ_OK;
-    RQ_HIP(e, hipMemcpy2DAsync(dst, (size_t)ld * 4, src, (size_t)e->ld * 4, (size_t)G * 4, n,
-                               hipMemcpyDeviceToHost, e->stream));
+    RQ_HIP(e, hipMemcpy2DAsync(dst, (size_t)ld * sizeof(T), src, (size_t)e->ld * sizeof(T),
+                               (size_t)G * sizeof(T), n, hipMemcpyDeviceToHost, e->stream));
     return RQ_OK;
 }
 int h2d(rq_engine *e, void *dst, const void *src, size_t bytes) {
@@ -93,16 +96,50 @@ int d2h(rq_engine *e, void *dst, const void *src, size_t bytes) {
 
 #define RQ_TRY(x) do { int rq_rc_ = (x); if (rq_rc_ != RQ_OK) return rq_rc_; } while (0)
 
+// The engine's staging buffers of one element width.  The 32-bit set is part
+// of the slab made at create time; the 64-bit set is allocated by the first
+// 64-bit host-buffer call and lives until the engine is destroyed.
+template <typename T> struct staging {
+    T *match, *voter_term, *voted_for, *last_log_term;            // planes [max_slots][ld]
+    T *commit, *leader_term, *cand_term, *cand_id, *max_term;     // per group [ld]
+    T *log_base;                                                  // per group [ld], 64-bit set only
+    T *log_term;                                                  // [max_log_terms]
+};
+
+int get_staging(rq_engine *e, staging<int32_t> &s) {
+    s = staging<int32_t>{e->match, e->voter_term, e->voted_for, e->last_log_term, e->commit,
+                         e->leader_term, e->cand_term, e->cand_id, e->max_term, nullptr, e->log_term};
+    return RQ_OK;
+}
+
+int get_staging(rq_engine *e, staging<int64_t> &s) {
+    const size_t plane = up((size_t)e->max_slots * e->ld * 8), vec = up((size_t)e->ld * 8);
+    const size_t arena = up((size_t)e->max_log_terms * 8 + 8);
+    if (!e->slab64) {
+        const size_t total = 4 * plane + 6 * vec + arena;
+        if (hipMalloc((void **)&e->slab64, total) != hipSuccess) { e->slab64 = nullptr; return RQ_E_NOMEM; }
+        RQ_HIP(e, hipMemsetAsync(e->slab64, 0, total, e->stream));
+    }
+    char *p = e->slab64;
+    auto take = [&p](size_t bytes) { char *r = p; p += bytes; return (int64_t *)r; };
+    s.match = take(plane); s.voter_term = take(plane); s.voted_for = take(plane); s.last_log_term = take(plane);
+    s.commit = take(vec); s.leader_term = take(vec); s.cand_term = take(vec); s.cand_id = take(vec);
+    s.max_term = take(vec); s.log_base = take(vec);
+    s.log_term = take(arena);
+    return RQ_OK;
+}
+
 // The CSR arena of one call: validates monotone offsets on the host copy the
 // caller already holds (the kernel indexes the arena with them).
-int stage_log(rq_engine *e, uint32_t G, const uint32_t *log_off, const int32_t *log_term) {
+template <typename T>
+int stage_log(rq_engine *e, const staging<T> &s, uint32_t G, const uint32_t *log_off, const T *log_term) {
     if (!log_off || (!log_term && G && log_off[G] != 0)) return RQ_E_ARG;
     for (uint32_t g = 0; g < G; g++)
         if (log_off[g + 1] < log_off[g]) return RQ_E_ARG;
     const uint64_t total = G ? (uint64_t)log_off[G] : 0;
     if (total > e->max_log_terms) return RQ_E_RANGE;
     RQ_TRY(h2d(e, e->log_off, log_off, ((size_t)G + 1) * 4));
-    RQ_TRY(h2d(e, e->log_term, log_term, (size_t)total * 4));
+    RQ_TRY(h2d(e, s.log_term, log_term, (size_t)total * sizeof(T)));
     return RQ_OK;
 }
 
@@ -114,40 +151,52 @@ int check_masks(uint32_t G, uint32_t m, const uint16_t *old_mask, const uint16_t
     return RQ_OK;
 }
 
-struct host_round {
+template <typename T>
+struct host_round_t {
     uint32_t G, n, ld;
     bool joint;
     const uint16_t *old_mask, *new_mask;
     // inputs
-    const int32_t *match, *commit, *leader_term;
+    const T *match, *commit, *leader_term;
     const uint32_t *log_off;
-    const int32_t *log_term;
-    const int32_t *voter_term, *voted_for, *last_log_term, *cand_term, *cand_id;
+    const T *log_term;
+    const T *log_base;   // 64-bit entry points only; may be null
+    const T *voter_term, *voted_for, *last_log_term, *cand_term, *cand_id;
     // outputs
-    int32_t *commit_out, *voter_term_out;
+    T *commit_out, *voter_term_out;
     uint16_t *grant_mask, *stepdown_mask;
     uint8_t *elected;
-    int32_t *max_term;
+    T *max_term;
     uint8_t *status_out;
 };
+typedef host_round_t<int32_t> host_round;
 
-rq_round_args device_args(rq_engine *e, uint32_t G, uint32_t m, bool joint) {
-    rq_round_args a;
+template <typename T>
+rq_round_args_t<T> device_args(rq_engine *e, const staging<T> &s, uint32_t G, uint32_t m, bool joint) {
+    rq_round_args_t<T> a;
     std::memset(&a, 0, sizeof a);
     a.G = G; a.ld = e->ld; a.m = m;
-    a.match = e->match; a.commit = e->commit; a.leader_term = e->leader_term;
-    a.log_off = e->log_off; a.log_term = e->log_term;
-    a.voter_term = e->voter_term; a.voted_for = e->voted_for;
-    a.last_log_term = e->last_log_term; a.cand_term = e->cand_term; a.cand_id = e->cand_id;
+    a.match = s.match; a.commit = s.commit; a.leader_term = s.leader_term;
+    a.log_off = e->log_off; a.log_term = s.log_term;
+    a.voter_term = s.voter_term; a.voted_for = s.voted_for;
+    a.last_log_term = s.last_log_term; a.cand_term = s.cand_term; a.cand_id = s.cand_id;
     a.old_mask = joint ? e->old_mask : nullptr;
     a.new_mask = joint ? e->new_mask : nullptr;
-    a.commit_out = e->commit; a.voter_term_out = e->voter_term;  // in place on device
+    a.commit_out = s.commit; a.voter_term_out = s.voter_term;  // in place on device
     a.grant_mask = e->grant; a.stepdown_mask = e->stepdown; a.elected = e->elected;
-    a.max_term = e->max_term; a.status_out = e->status; a.elected_bits = nullptr;
+    a.max_term = s.max_term; a.status_out = e->status; a.elected_bits = nullptr;
     return a;
 }
 
-int stage_inputs(rq_engine *e, const host_round &h, int what) {
+rq_round_args device_args(rq_engine *e, uint32_t G, uint32_t m, bool joint) {
+    staging<int32_t> s;
+    (void)get_staging(e, s);
+    return device_args(e, s, G, m, joint);
+}
+
+template <typename T>
+int stage_inputs(rq_engine *e, const staging<T> &s, const host_round_t<T> &h, int what) {
+    const size_t E = sizeof(T);
     if (h.joint) {
         RQ_TRY(check_masks(h.G, h.n, h.old_mask, h.new_mask));
         RQ_TRY(h2d(e, e->old_mask, h.old_mask, (size_t)h.G * 2));
@@ -155,41 +204,52 @@ int stage_inputs(rq_engine *e, const host_round &h, int what) {
     }
     if (what & RQ_WHAT_COMMIT) {
         if (!h.match || !h.commit || !h.leader_term) return RQ_E_ARG;
-        RQ_TRY(stage_log(e, h.G, h.log_off, h.log_term));
-        RQ_TRY(h2d_planes(e, e->match, h.match, h.G, h.n, h.ld));
-        RQ_TRY(h2d(e, e->commit, h.commit, (size_t)h.G * 4));
-        RQ_TRY(h2d(e, e->leader_term, h.leader_term, (size_t)h.G * 4));
+        RQ_TRY(stage_log(e, s, h.G, h.log_off, h.log_term));
+        RQ_TRY(h2d_planes(e, s.match, h.match, h.G, h.n, h.ld));
+        RQ_TRY(h2d(e, s.commit, h.commit, (size_t)h.G * E));
+        RQ_TRY(h2d(e, s.leader_term, h.leader_term, (size_t)h.G * E));
+        if (h.log_base) RQ_TRY(h2d(e, s.log_base, h.log_base, (size_t)h.G * E));
     }
     if (what & RQ_WHAT_VOTE) {
         if (!h.voter_term || !h.voted_for || !h.last_log_term || !h.cand_term || !h.cand_id)
             return RQ_E_ARG;
-        RQ_TRY(h2d_planes(e, e->voter_term, h.voter_term, h.G, h.n, h.ld));
-        RQ_TRY(h2d_planes(e, e->voted_for, h.voted_for, h.G, h.n, h.ld));
-        RQ_TRY(h2d_planes(e, e->last_log_term, h.last_log_term, h.G, h.n, h.ld));
-        RQ_TRY(h2d(e, e->cand_term, h.cand_term, (size_t)h.G * 4));
-        RQ_TRY(h2d(e, e->cand_id, h.cand_id, (size_t)h.G * 4));
+        RQ_TRY(h2d_planes(e, s.voter_term, h.voter_term, h.G, h.n, h.ld));
+        RQ_TRY(h2d_planes(e, s.voted_for, h.voted_for, h.G, h.n, h.ld));
+        RQ_TRY(h2d_planes(e, s.last_log_term, h.last_log_term, h.G, h.n, h.ld));
+        RQ_TRY(h2d(e, s.cand_term, h.cand_term, (size_t)h.G * E));
+        RQ_TRY(h2d(e, s.cand_id, h.cand_id, (size_t)h.G * E));
     }
     return RQ_OK;
 }
 
-int fetch_outputs(rq_engine *e, const host_round &h, int what) {
-    if (what & RQ_WHAT_COMMIT) RQ_TRY(d2h(e, h.commit_out, e->commit, (size_t)h.G * 4));
+int stage_inputs(rq_engine *e, const host_round &h, int what) {
+    staging<int32_t> s;
+    (void)get_staging(e, s);
+    return stage_inputs(e, s, h, what);
+}
+
+template <typename T>
+int fetch_outputs(rq_engine *e, const staging<T> &s, const host_round_t<T> &h, int what) {
+    const size_t E = sizeof(T);
+    if (what & RQ_WHAT_COMMIT) RQ_TRY(d2h(e, h.commit_out, s.commit, (size_t)h.G * E));
     if (what & RQ_WHAT_VOTE) {
         // Joint rounds: a non-member slot on the device still holds the staged
         // input (the kernel leaves it alone or rewrites the value it loaded), so
         // whole-plane copies hand the caller its own value back for those slots.
-        RQ_TRY(d2h_planes(e, h.voter_term_out, e->voter_term, h.G, h.n, h.ld));
+        RQ_TRY(d2h_planes(e, h.voter_term_out, s.voter_term, h.G, h.n, h.ld));
         RQ_TRY(d2h(e, h.grant_mask, e->grant, (size_t)h.G * 2));
         RQ_TRY(d2h(e, h.stepdown_mask, e->stepdown, (size_t)h.G * 2));
         RQ_TRY(d2h(e, h.elected, e->elected, (size_t)h.G));
-        RQ_TRY(d2h(e, h.max_term, e->max_term, (size_t)h.G * 4));
+        RQ_TRY(d2h(e, h.max_term, s.max_term, (size_t)h.G * E));
     }
     RQ_TRY(d2h(e, h.status_out, e->status, (size_t)h.G));
     return RQ_OK;
 }
 
-int run_host_round(rq_engine *e, const host_round &h, int what) {
+template <typename T>
+int run_host_round(rq_engine *e, const host_round_t<T> &h, int what) {
     RQ_TRY(check_shape(e, h.G, h.n, h.ld));
+    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (what & ~(RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return RQ_E_ARG;
     if ((what & RQ_WHAT_COMMIT) && !h.commit_out) return RQ_E_ARG;
     if ((what & RQ_WHAT_VOTE) &&
         (!h.voter_term_out || !h.grant_mask || !h.stepdown_mask || !h.elected || !h.max_term))
@@ -198,11 +258,34 @@ int run_host_round(rq_engine *e, const host_round &h, int what) {
     RQ_HIP(e, hipSetDevice(e->device));
     e->resident = false;
     if (h.G == 0) return RQ_OK;
-    RQ_TRY(stage_inputs(e, h, what));
-    rq_round_args a = device_args(e, h.G, h.n, h.joint);
+    staging<T> s;
+    RQ_TRY(get_staging(e, s));
+    RQ_TRY(stage_inputs(e, s, h, what));
+    rq_round_args_t<T> a = device_args(e, s, h.G, h.n, h.joint);
+    if ((what & RQ_WHAT_COMMIT) && h.log_base) a.log_base = s.log_base;
     RQ_HIP(e, rq_launch_round(a, h.n, h.joint, what, 0, e->stream));
-    RQ_TRY(fetch_outputs(e, h, what));
+    RQ_TRY(fetch_outputs(e, s, h, what));
     RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+template <typename T>
+int dev_launch(rq_engine *e, void *stream, int variant, uint32_t n, bool joint, int what,
+                      const rq_round_args_t<T> &a) {
+    if (!e) return RQ_E_ARG;
+    if (n < 1 || n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
+    if (what & RQ_WHAT_COMMIT)
+        if (!a.match || !a.commit || !a.leader_term || !a.log_off || !a.log_term || !a.commit_out)
+            return RQ_E_ARG;
+    if (what & RQ_WHAT_VOTE)
+        if (!a.voter_term || !a.voted_for || !a.last_log_term || !a.cand_term || !a.cand_id ||
+            !a.voter_term_out || !a.grant_mask || !a.stepdown_mask || !a.elected || !a.max_term)
+            return RQ_E_ARG;
+    if (joint && (!a.old_mask || !a.new_mask)) return RQ_E_ARG;
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipError_t err = rq_launch_round(a, n, joint, what, variant, (hipStream_t)stream);
+    if (err == hipErrorInvalidValue) return RQ_E_ARG;
+    RQ_HIP(e, err);
     return RQ_OK;
 }
 
@@ -297,6 +380,7 @@ int rq_engine_destroy(rq_engine *e) {
             if (hipStreamDestroy(e->stream) != hipSuccess) rc = RQ_E_HIP;
         }
         if (e->slab && hipFree(e->slab) != hipSuccess) rc = RQ_E_HIP;
+        if (e->slab64 && hipFree(e->slab64) != hipSuccess) rc = RQ_E_HIP;
         if (e->aux && hipFree(e->aux) != hipSuccess) rc = RQ_E_HIP;
         if (e->step_graph) (void)hipGraphExecDestroy(e->step_graph);
     }
@@ -612,25 +696,6 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
 
 // ---- device-pointer launches ----------------------------------------------
 
-static int dev_launch(rq_engine *e, void *stream, int variant, uint32_t n, bool joint, int what,
-                      const rq_round_args &a) {
-    if (!e) return RQ_E_ARG;
-    if (n < 1 || n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
-    if (what & RQ_WHAT_COMMIT)
-        if (!a.match || !a.commit || !a.leader_term || !a.log_off || !a.log_term || !a.commit_out)
-            return RQ_E_ARG;
-    if (what & RQ_WHAT_VOTE)
-        if (!a.voter_term || !a.voted_for || !a.last_log_term || !a.cand_term || !a.cand_id ||
-            !a.voter_term_out || !a.grant_mask || !a.stepdown_mask || !a.elected || !a.max_term)
-            return RQ_E_ARG;
-    if (joint && (!a.old_mask || !a.new_mask)) return RQ_E_ARG;
-    RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = rq_launch_round(a, n, joint, what, variant, (hipStream_t)stream);
-    if (err == hipErrorInvalidValue) return RQ_E_ARG;
-    RQ_HIP(e, err);
-    return RQ_OK;
-}
-
 int rq_fused_round_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n, uint32_t ld,
                        const int32_t *match, const int32_t *commit, const int32_t *leader_term,
                        const uint32_t *log_off, const int32_t *log_term,
@@ -713,6 +778,58 @@ int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G
     a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
     a.log_base = log_base;
     return dev_launch(e, stream, variant, m, true, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
+}
+
+// ---- wide layout ----------------------------------------------------------
+
+int rq_round64(rq_engine *e, int what, uint32_t G, uint32_t m, uint32_t ld,
+               const uint16_t *old_mask, const uint16_t *new_mask,
+               const int64_t *match, const int64_t *commit, const int64_t *leader_term,
+               const uint32_t *log_off, const int64_t *log_term, const int64_t *log_base,
+               const int64_t *voter_term, const int64_t *voted_for,
+               const int64_t *voter_last_log_term, const int64_t *cand_term,
+               const int64_t *cand_id, int64_t *commit_out, int64_t *voter_term_out,
+               uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
+               int64_t *max_term, uint8_t *status_out) {
+    if ((old_mask == nullptr) != (new_mask == nullptr)) return RQ_E_ARG;
+    host_round_t<int64_t> h{};
+    h.G = G; h.n = m; h.ld = ld; h.joint = old_mask != nullptr; h.old_mask = old_mask; h.new_mask = new_mask;
+    h.match = match; h.commit = commit; h.leader_term = leader_term;
+    h.log_off = log_off; h.log_term = log_term; h.log_base = log_base;
+    h.voter_term = voter_term; h.voted_for = voted_for; h.last_log_term = voter_last_log_term;
+    h.cand_term = cand_term; h.cand_id = cand_id;
+    h.commit_out = commit_out; h.voter_term_out = voter_term_out; h.grant_mask = grant_mask;
+    h.stepdown_mask = stepdown_mask; h.elected = elected; h.max_term = max_term;
+    h.status_out = status_out;
+    return run_host_round(e, h, what);
+}
+
+int rq_round64_dev(rq_engine *e, void *stream, int variant, int what, uint32_t G, uint32_t m,
+                   uint32_t ld, const uint16_t *old_mask, const uint16_t *new_mask,
+                   const int64_t *match, const int64_t *commit, const int64_t *leader_term,
+                   const uint32_t *log_off, const int64_t *log_term, const int64_t *log_base,
+                   const int64_t *voter_term, const int64_t *voted_for,
+                   const int64_t *voter_last_log_term, const int64_t *cand_term,
+                   const int64_t *cand_id, int64_t *commit_out, int64_t *voter_term_out,
+                   uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
+                   int64_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
+                   uint16_t *commit_lo16, const int64_t *summary_base,
+                   uint32_t *summary_escapes) {
+    if ((old_mask == nullptr) != (new_mask == nullptr)) return RQ_E_ARG;
+    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (what & ~(RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return RQ_E_ARG;
+    rq_round64_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.m = m;
+    a.old_mask = old_mask; a.new_mask = new_mask;
+    a.match = match; a.commit = commit; a.leader_term = leader_term;
+    a.log_off = log_off; a.log_term = log_term; a.log_base = log_base;
+    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
+    a.cand_term = cand_term; a.cand_id = cand_id;
+    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
+    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
+    a.status_out = status_out; a.elected_bits = elected_bits;
+    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
+    return dev_launch(e, stream, variant, m, old_mask != nullptr, what, a);
 }
 
 int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out) {

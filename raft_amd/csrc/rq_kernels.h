@@ -5,42 +5,47 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// One round's device pointers.  Planes are field[p * ld + g].
-struct rq_round_args {
+// One round's device pointers.  Planes are field[p * ld + g].  T is the
+// element type of every term, index and id: int32_t (the compact layout) or
+// int64_t (Go's int on amd64, raft.go:35-68).
+template <typename T>
+struct rq_round_args_t {
     uint32_t G;
     uint32_t ld;
     uint32_t m;  // joint kernels: number of slot planes
     // commit side (Node.matchIndex / commitIndex / currentTerm / log, raft.go:35-68)
-    const int32_t  *match;
-    const int32_t  *commit;
-    const int32_t  *leader_term;
+    const T *match;
+    const T *commit;
+    const T *leader_term;
     const uint32_t *log_off;
-    const int32_t  *log_term;
-    const int32_t  *log_base;    // may be null (0): arena slot 0 of group g holds log[log_base[g]]
+    const T *log_term;
+    const T *log_base;    // may be null (0): arena slot 0 of group g holds log[log_base[g]]
     // vote side (RequestVoteRPC inputs, raft.go:181-210)
-    const int32_t  *voter_term;
-    const int32_t  *voted_for;
-    const int32_t  *last_log_term;
-    const int32_t  *cand_term;
-    const int32_t  *cand_id;
+    const T *voter_term;
+    const T *voted_for;
+    const T *last_log_term;
+    const T *cand_term;
+    const T *cand_id;
     // joint consensus member masks
     const uint16_t *old_mask;
     const uint16_t *new_mask;
     // outputs
-    int32_t  *commit_out;
-    int32_t  *voter_term_out;
+    T *commit_out;
+    T *voter_term_out;
     uint16_t *grant_mask;
     uint16_t *stepdown_mask;
     uint8_t  *elected;
-    int32_t  *max_term;
+    T *max_term;
     uint8_t  *status_out;    // may be null
     uint64_t *elected_bits;  // may be null
     // narrow summary for the sharded exchange (all may be null):
     // commit_lo16[g] = commit'[g] - summary_base[g] if that is in [0, 65535), else 65535
     uint16_t *commit_lo16;
-    const int32_t *summary_base;   // null = 0
+    const T *summary_base;         // null = 0
     uint32_t *summary_escapes;     // incremented once per group that did not fit
 };
+typedef rq_round_args_t<int32_t> rq_round_args;
+typedef rq_round_args_t<int64_t> rq_round64_args;
 
 // Kernel build selector ("variant" in the C-ABI).  Never changes results.
 //   0         library default for the kernel family (see RQ_VAR_DEFAULT_*)
@@ -70,6 +75,10 @@ struct rq_round_args {
 // n is the fixed cluster size (1..16) or, with joint = true, ignored in favour
 // of a.m and the masks.  Returns hipErrorInvalidValue for shapes it rejects.
 hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint,
+                           int what, int variant, hipStream_t stream);
+// The same round over 64-bit planes.  Builds: one group per thread; variant
+// bits 4-6 and 8-11 are honoured, the others ignored.
+hipError_t rq_launch_round(const rq_round64_args &a, uint32_t n, bool joint,
                            int what, int variant, hipStream_t stream);
 
 // AppendEntries receiver-side consistency batch (raft.go:142-153) plus the

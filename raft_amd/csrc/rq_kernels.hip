@@ -1,673 +1,11 @@
-// rq_kernels.hip -- gfx950 (MI355X) kernels of the batched Raft quorum engine.
-//
-// One thread owns V consecutive groups (V = 1, 2 or 4) so that every plane is
-// read with one 4*V-byte load per lane: a wave reads 256*V contiguous bytes of
-// each slot plane, and the 2-byte / 1-byte per-group outputs become 4- or
-// 8-byte stores.  All quorum arithmetic stays in registers:
-//   * commit: compile-time sorting network over the n matchIndex values
-//     (v_min/v_max/v_med3), one gathered log-term load, one compare;
-//   * vote: the reference's RequestVoteRPC predicate per slot (raft.go:181-223)
-//     folded into two bit masks, popcount majority, running max of terms.
-// The kernels are HBM-bound integer work; there is no matrix-shaped step.
-#include "rq_kernels.h"
+// rq_kernels.hip -- gfx950 (MI355X) kernels of the batched Raft quorum engine,
+// 32-bit layout: the quorum round (rq_round_impl.h instantiated for int32_t),
+// the AppendEntries consistency batch and the follower commit clamp.
+#include "rq_round_impl.h"
 
 #include <limits.h>
 
 namespace {
-
-constexpr int kBlock = 256;
-constexpr int kLdsLogCap = 4096;  // int32 entries of log arena staged per block (16 KiB)
-
-// ---------------------------------------------------------------------------
-// vector load/store helpers
-// ---------------------------------------------------------------------------
-template <int V> struct i32v;
-template <> struct i32v<2> { typedef int32_t type __attribute__((ext_vector_type(2))); };
-template <> struct i32v<4> { typedef int32_t type __attribute__((ext_vector_type(4))); };
-
-// r[0..V) = p[0..V) (FULL: one aligned vector load; else first `valid` only).
-template <int V, bool NT, bool FULL>
-__device__ __forceinline__ void ld_i32(const int32_t *p, int valid, int32_t (&r)[V]) {
-    if constexpr (!FULL) {
-#pragma unroll
-        for (int k = 0; k < V; k++) r[k] = k < valid ? p[k] : 0;
-    } else if constexpr (V == 1) {
-        r[0] = NT ? __builtin_nontemporal_load(p) : *p;
-    } else {
-        typedef typename i32v<V>::type vt;
-        const vt *vp = reinterpret_cast<const vt *>(p);
-        vt v = NT ? __builtin_nontemporal_load(vp) : *vp;
-#pragma unroll
-        for (int k = 0; k < V; k++) r[k] = v[k];
-    }
-}
-
-template <int V, bool NT, bool FULL>
-__device__ __forceinline__ void st_i32(int32_t *p, int valid, const int32_t (&r)[V]) {
-    if constexpr (!FULL) {
-#pragma unroll
-        for (int k = 0; k < V; k++) if (k < valid) p[k] = r[k];
-    } else if constexpr (V == 1) {
-        if (NT) __builtin_nontemporal_store(r[0], p); else *p = r[0];
-    } else {
-        typedef typename i32v<V>::type vt;
-        vt v;
-#pragma unroll
-        for (int k = 0; k < V; k++) v[k] = r[k];
-        vt *vp = reinterpret_cast<vt *>(p);
-        if (NT) __builtin_nontemporal_store(v, vp); else *vp = v;
-    }
-}
-
-// V 16-bit values (low halves of r[k]) -> one 2*V-byte store.
-template <int V, bool NT, bool FULL>
-__device__ __forceinline__ void st_u16(uint16_t *p, int valid, const uint32_t (&r)[V]) {
-    if constexpr (!FULL) {
-#pragma unroll
-        for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint16_t)r[k];
-    } else if constexpr (V == 1) {
-        if (NT) __builtin_nontemporal_store((uint16_t)r[0], p); else *p = (uint16_t)r[0];
-    } else if constexpr (V == 2) {
-        uint32_t w = (r[0] & 0xFFFFu) | (r[1] << 16);
-        uint32_t *wp = reinterpret_cast<uint32_t *>(p);
-        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
-    } else {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 w;
-        w[0] = (r[0] & 0xFFFFu) | (r[1] << 16);
-        w[1] = (r[2] & 0xFFFFu) | (r[3] << 16);
-        u32x2 *wp = reinterpret_cast<u32x2 *>(p);
-        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
-    }
-}
-
-// V 8-bit values -> one V-byte store.
-template <int V, bool NT, bool FULL>
-__device__ __forceinline__ void st_u8(uint8_t *p, int valid, const uint32_t (&r)[V]) {
-    if constexpr (!FULL) {
-#pragma unroll
-        for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint8_t)r[k];
-    } else if constexpr (V == 1) {
-        if (NT) __builtin_nontemporal_store((uint8_t)r[0], p); else *p = (uint8_t)r[0];
-    } else if constexpr (V == 2) {
-        const uint16_t w = (uint16_t)((r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8));
-        uint16_t *wp = reinterpret_cast<uint16_t *>(p);
-        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
-    } else {
-        uint32_t w = (r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8) | ((r[2] & 0xFFu) << 16) | (r[3] << 24);
-        uint32_t *wp = reinterpret_cast<uint32_t *>(p);
-        if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
-    }
-}
-
-template <int V, bool FULL>
-__device__ __forceinline__ void ld_u16(const uint16_t *p, int valid, uint32_t (&r)[V]) {
-    if constexpr (!FULL) {
-#pragma unroll
-        for (int k = 0; k < V; k++) r[k] = k < valid ? p[k] : 0;
-    } else if constexpr (V == 1) {
-        r[0] = *p;
-    } else if constexpr (V == 2) {
-        uint32_t w = *reinterpret_cast<const uint32_t *>(p);
-        r[0] = w & 0xFFFFu; r[1] = w >> 16;
-    } else {
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 w = *reinterpret_cast<const u32x2 *>(p);
-        r[0] = w[0] & 0xFFFFu; r[1] = w[0] >> 16;
-        r[2] = w[1] & 0xFFFFu; r[3] = w[1] >> 16;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// quorum index: ascending_sorted(s)[(N-1)/2] = the (N/2+1)-th largest value,
-// i.e. the largest index replicated on a strict majority of the N slots.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void cex(int32_t &a, int32_t &b) {
-    int32_t lo = min(a, b), hi = max(a, b);
-    a = lo; b = hi;
-}
-__device__ __forceinline__ int32_t med3(int32_t a, int32_t b, int32_t c) {
-    return max(min(a, b), min(max(a, b), c));  // folds to v_med3_i32
-}
-
-template <int N>
-__device__ __forceinline__ int32_t quorum_index(int32_t (&s)[N]) {
-    if constexpr (N == 1) {
-        return s[0];
-    } else if constexpr (N == 2) {
-        return min(s[0], s[1]);
-    } else if constexpr (N == 3) {
-        return med3(s[0], s[1], s[2]);
-    } else if constexpr (N == 4) {
-        return min(max(min(s[0], s[1]), min(s[2], s[3])),
-                   min(max(s[0], s[1]), max(s[2], s[3])));
-    } else if constexpr (N == 5) {
-        return med3(s[4], max(min(s[0], s[1]), min(s[2], s[3])),
-                          min(max(s[0], s[1]), max(s[2], s[3])));
-    } else if constexpr (N == 6) {
-        cex(s[0], s[5]); cex(s[1], s[3]); cex(s[2], s[4]);
-        cex(s[1], s[2]); cex(s[3], s[4]);
-        cex(s[0], s[3]); cex(s[2], s[5]);
-        cex(s[0], s[1]); cex(s[2], s[3]); cex(s[4], s[5]);
-        cex(s[1], s[2]); cex(s[3], s[4]);
-        return s[2];
-    } else if constexpr (N == 7) {
-        cex(s[0], s[6]); cex(s[2], s[3]); cex(s[4], s[5]);
-        cex(s[0], s[2]); cex(s[1], s[4]); cex(s[3], s[6]);
-        cex(s[0], s[1]); cex(s[2], s[5]); cex(s[3], s[4]);
-        cex(s[1], s[2]); cex(s[4], s[6]);
-        cex(s[2], s[3]); cex(s[4], s[5]);
-        cex(s[1], s[2]); cex(s[3], s[4]); cex(s[5], s[6]);
-        return s[3];
-    } else if constexpr (N == 8) {
-        cex(s[0], s[2]); cex(s[1], s[3]); cex(s[4], s[6]); cex(s[5], s[7]);
-        cex(s[0], s[4]); cex(s[1], s[5]); cex(s[2], s[6]); cex(s[3], s[7]);
-        cex(s[0], s[1]); cex(s[2], s[3]); cex(s[4], s[5]); cex(s[6], s[7]);
-        cex(s[2], s[4]); cex(s[3], s[5]);
-        cex(s[1], s[4]); cex(s[3], s[6]);
-        cex(s[1], s[2]); cex(s[3], s[4]); cex(s[5], s[6]);
-        return s[3];
-    } else {
-        static_assert(N == 9, "fixed-size networks cover 1..9 slots");
-        cex(s[0], s[3]); cex(s[1], s[7]); cex(s[2], s[5]); cex(s[4], s[8]);
-        cex(s[0], s[7]); cex(s[2], s[4]); cex(s[3], s[8]); cex(s[5], s[6]);
-        cex(s[0], s[2]); cex(s[1], s[3]); cex(s[4], s[5]); cex(s[7], s[8]);
-        cex(s[1], s[4]); cex(s[3], s[6]); cex(s[5], s[7]);
-        cex(s[0], s[1]); cex(s[2], s[4]); cex(s[3], s[5]); cex(s[6], s[8]);
-        cex(s[2], s[3]); cex(s[4], s[5]); cex(s[6], s[7]);
-        cex(s[1], s[2]); cex(s[3], s[4]); cex(s[5], s[6]);
-        return s[4];
-    }
-}
-
-// ---------------------------------------------------------------------------
-// One RequestVoteRPC evaluation (raft.go:181-210 with :212-223 and :234-236).
-//   stepdown : term > cur                         (:219, role := Follower :221)
-//   cur2     : max(cur, term)                     (:220)
-//   reach    : !(term < cur2) == term >= cur      (:190)
-//   grant    : reach && (votedFor == -1 || votedFor == candId)   (:202-203)
-//                    && lastEntry(log).TermNum <= term           (:204)
-//   panic    : reach && log empty                 (:204 -> :235 index panic)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void vote_slot(int32_t cur, int32_t vf, int32_t llt,
-                                          int32_t term, int32_t cid, int32_t &cur2,
-                                          uint32_t &stepdown, uint32_t &grant,
-                                          uint32_t &panic) {
-    // bitwise on purpose: && / || compile to a chain of divergent branches
-    stepdown = (uint32_t)(term > cur);
-    cur2 = max(cur, term);
-    const uint32_t reach = (uint32_t)(term >= cur);
-    const uint32_t empty = (uint32_t)(llt == INT_MIN);
-    const uint32_t free_vote = (uint32_t)(vf == -1) | (uint32_t)(vf == cid);
-    panic = reach & empty;
-    grant = reach & free_vote & (empty ^ 1u) & (uint32_t)(llt <= term);
-}
-
-// Pack each thread's V elected bits (groups g0..g0+V-1) into the 1-bit-per-
-// group summary.  Must be reached by every lane of the wave.
-template <int V>
-__device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32_t G,
-                                             uint64_t *bits) {
-    if constexpr (V == 1) {
-        unsigned long long w = __ballot(field & 1u);
-        if ((threadIdx.x & 63) == 0 && g0 < G) bits[g0 >> 6] = w;
-    } else {
-        constexpr int lanes_per_word = 64 / V;
-        unsigned long long w = (unsigned long long)field << (g0 & 63);
-#pragma unroll
-        for (int o = lanes_per_word / 2; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
-        if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) bits[g0 >> 6] = w;
-    }
-}
-
-constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02;
-
-// The one dependent, data-indexed load of a round: log[N].TermNum.  The cache
-// policy is a compile-time choice: with a run-time flag the compiler merges
-// the two loads and drops the non-temporal hint.
-template <bool NT>
-__device__ __forceinline__ int32_t gather_term(const int32_t *p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
-}
-
-// 16-bit window of the commit summary: offset from a per-group base, 65535 =
-// "does not fit, fetch the full vector" (counted in summary_escapes).
-template <int V, bool NTS, bool FULL>
-__device__ __forceinline__ void store_commit_lo16(const rq_round_args &a, uint32_t g0, int valid,
-                                                  const int32_t (&co)[V]) {
-    uint32_t lo[V];
-    uint32_t escapes = 0;
-#pragma unroll
-    for (int k = 0; k < V; k++) {
-        const int32_t base = (a.summary_base && k < valid) ? a.summary_base[g0 + k] : 0;
-        const long long d = (long long)co[k] - (long long)base;
-        const bool fit = d >= 0 && d < 65535;
-        lo[k] = fit ? (uint32_t)d : 65535u;
-        escapes += (!fit && k < valid) ? 1u : 0u;
-    }
-    st_u16<V, NTS, FULL>(a.commit_lo16 + g0, valid, lo);
-    if (escapes && a.summary_escapes) atomicAdd(a.summary_escapes, escapes);
-}
-
-// ---------------------------------------------------------------------------
-// fixed cluster size n = N for every group
-// ---------------------------------------------------------------------------
-template <int N, int V, int WHAT, int FLAGS, bool FULL>
-__device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args &a,
-                                                     uint32_t g0, int valid,
-                                                     const int32_t *lds_log, uint32_t lds_seg0) {
-    constexpr bool NTL = (FLAGS & RQ_VAR_NT_LOAD) != 0;
-    constexpr bool NTS = (FLAGS & RQ_VAR_NT_STORE) != 0;
-    constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
-    constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
-    const size_t ld = a.ld;
-
-    int32_t mt[N][V], cm[V], lt[V], off[V + 1], lb[V];
-#pragma unroll
-    for (int k = 0; k < V; k++) lb[k] = 0;
-    int32_t vt[N][V], vf[N][V], ll[N][V], ct[V], ci[V];
-    uint32_t st[V];
-#pragma unroll
-    for (int k = 0; k < V; k++) st[k] = 0;
-
-    // ---- issue every streamed load up front ----
-    if constexpr (DO_COMMIT) {
-#pragma unroll
-        for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
-        ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
-        ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
-        if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
-        const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
-        int32_t o[V];
-        ld_i32<V, NTL, FULL>(offp, valid, o);
-        // plain on purpose: it re-reads the line the vector load above brought in
-        // (non-temporal here bypasses L1 and was measured 1 us slower per round)
-        const int32_t oend = offp[valid];  // log_off has G+1 entries
-#pragma unroll
-        for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
-        off[V] = oend;
-    }
-    if constexpr (DO_VOTE) {
-#pragma unroll
-        for (int p = 0; p < N; p++) {
-            ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, vt[p]);
-            ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, vf[p]);
-            ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, ll[p]);
-        }
-        ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
-        ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
-    }
-
-    // ---- commit: quorum index, then the dependent log-term gather ----
-    int32_t nq[V], gt[V];
-    bool adv[V], inb[V];
-    if constexpr (DO_COMMIT) {
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            int32_t s[N];
-#pragma unroll
-            for (int p = 0; p < N; p++) s[p] = mt[p][k];
-            nq[k] = quorum_index<N>(s);
-            const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
-            // window: arena slot i of the group holds log[base + i]; N below the base wraps
-            // to a huge unsigned value and is reported like any other N outside the arena
-            const uint32_t wi = (uint32_t)nq[k] - (uint32_t)lb[k];
-            adv[k] = (k < valid) && nq[k] > cm[k];
-            inb[k] = wi < len;
-            gt[k] = 0;
-            if (adv[k] && inb[k]) {
-                if ((FLAGS & RQ_VAR_LDS_LOG) && lds_log)   // the block's arena segment is in LDS
-                    gt[k] = lds_log[(uint32_t)off[k] - lds_seg0 + wi];
-                else
-                    gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + wi));
-            }
-        }
-    }
-
-    // ---- vote: per-slot predicate, tally ----
-    uint32_t el_field = 0;
-    if constexpr (DO_VOTE) {
-        uint32_t gm[V], sm[V], el[V];
-        int32_t mx[V];
-#pragma unroll
-        for (int k = 0; k < V; k++) { gm[k] = 0; sm[k] = 0; mx[k] = INT_MIN; }
-#pragma unroll
-        for (int p = 0; p < N; p++) {
-            int32_t nt[V];
-#pragma unroll
-            for (int k = 0; k < V; k++) {
-                uint32_t sd, gr, pn;
-                vote_slot(vt[p][k], vf[p][k], ll[p][k], ct[k], ci[k], nt[k], sd, gr, pn);
-                gm[k] |= gr << p;
-                sm[k] |= sd << p;
-                mx[k] = max(mx[k], nt[k]);
-                st[k] |= pn ? kStEmptyLog : 0;
-            }
-            st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
-        }
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            el[k] = (2 * __popc(gm[k]) > N) && (mx[k] == ct[k]);
-            if (k < valid) el_field |= el[k] << k;
-        }
-        st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
-        st_u16<V, NTS, FULL>(a.stepdown_mask + g0, valid, sm);
-        st_u8<V, NTS, FULL>(a.elected + g0, valid, el);
-        st_i32<V, NTS, FULL>(a.max_term + g0, valid, mx);
-    }
-
-    // ---- commit: finish ----
-    if constexpr (DO_COMMIT) {
-        int32_t co[V];
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
-            st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
-        }
-        st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
-        if (a.commit_lo16) store_commit_lo16<V, NTS, FULL>(a, g0, valid, co);
-    }
-    if (a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return el_field;
-}
-
-template <int N, int V, int WHAT, int FLAGS>
-__global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args a) {
-    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-    const int32_t *lds_log = nullptr;
-    uint32_t lds_seg0 = 0;
-    if constexpr ((FLAGS & RQ_VAR_LDS_LOG) != 0 && (WHAT & RQ_WHAT_COMMIT) != 0) {
-        // Stage the block's contiguous slice of the log arena (groups are in CSR
-        // order) through LDS with coalesced loads; the per-group log[N] lookup
-        // then reads LDS.  Blocks whose slice exceeds the buffer gather from
-        // global memory as usual.  All conditions here are block-uniform.
-        __shared__ int32_t staged[kLdsLogCap];
-        const uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x * V;
-        if (b0 < a.G) {
-            const uint64_t b1 = min(b0 + (uint64_t)blockDim.x * V, (uint64_t)a.G);
-            const uint32_t s0 = a.log_off[b0], s1 = a.log_off[b1];
-            if (s1 - s0 <= (uint32_t)kLdsLogCap) {
-                for (uint32_t i = threadIdx.x; i < s1 - s0; i += blockDim.x)
-                    staged[i] = __builtin_nontemporal_load(a.log_term + s0 + i);
-                lds_log = staged;
-                lds_seg0 = s0;
-            }
-        }
-        __syncthreads();
-    }
-    uint32_t el_field = 0;
-    if (g0 + V <= a.G)
-        el_field = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, lds_log, lds_seg0);
-    else if (g0 < a.G)
-        el_field = round_fixed_body<N, V, WHAT, FLAGS, false>(a, (uint32_t)g0, (int)(a.G - g0), lds_log, lds_seg0);
-    if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
-        if (a.elected_bits) pack_elected<V>(el_field, g0, a.G, a.elected_bits);
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Quorum index over a member subset: non-members are replaced by INT_MIN, the
-// vector is sorted in DESCENDING order by a Batcher odd-even merge network
-// (19 compare-exchanges for 8 inputs, 63 for 16) and element |cfg|/2 -- the
-// (|cfg|/2+1)-th largest member value -- is selected.
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void cexd(int32_t &a, int32_t &b) {
-    int32_t hi = max(a, b), lo = min(a, b);
-    a = hi; b = lo;
-}
-#define D(i, j) cexd(s[i], s[j]);
-__device__ __forceinline__ void sort_desc8(int32_t (&s)[8]) {
-    D(0,1) D(2,3) D(4,5) D(6,7) D(0,2) D(1,3) D(4,6) D(5,7) D(1,2) D(5,6) D(0,4) D(1,5) D(2,6)
-    D(3,7) D(2,4) D(3,5) D(1,2) D(3,4) D(5,6)
-}
-__device__ __forceinline__ void sort_desc16(int32_t (&s)[16]) {
-    D(0,1) D(2,3) D(4,5) D(6,7) D(8,9) D(10,11) D(12,13) D(14,15) D(0,2) D(1,3) D(4,6) D(5,7)
-    D(8,10) D(9,11) D(12,14) D(13,15) D(1,2) D(5,6) D(9,10) D(13,14) D(0,4) D(1,5) D(2,6)
-    D(3,7) D(8,12) D(9,13) D(10,14) D(11,15) D(2,4) D(3,5) D(10,12) D(11,13) D(1,2) D(3,4)
-    D(5,6) D(9,10) D(11,12) D(13,14) D(0,8) D(1,9) D(2,10) D(3,11) D(4,12) D(5,13) D(6,14)
-    D(7,15) D(4,8) D(5,9) D(6,10) D(7,11) D(2,4) D(3,5) D(6,8) D(7,9) D(10,12) D(11,13) D(1,2)
-    D(3,4) D(5,6) D(7,8) D(9,10) D(11,12) D(13,14)
-}
-#undef D
-
-// W = 8 or 16 slots considered; mask has no bit at or above W.
-template <int W, int MMAX, int V>
-__device__ __forceinline__ int32_t masked_quorum(const int32_t (&mt)[MMAX][V], int k, uint32_t mask) {
-    int32_t s[W];
-#pragma unroll
-    for (int p = 0; p < W; p++) s[p] = ((mask >> p) & 1u) ? mt[p][k] : INT_MIN;
-    if constexpr (W == 8) sort_desc8(s); else sort_desc16(s);
-    const int idx = __popc(mask) >> 1;
-    int32_t r = s[0];
-#pragma unroll
-    for (int i = 1; i <= W / 2; i++) r = (idx == i) ? s[i] : r;
-    return r;
-}
-
-// ---------------------------------------------------------------------------
-// per-group membership: m slot planes, old/new member masks (joint consensus,
-// mixed cluster sizes).  Null masks mean "all m slots, one configuration".
-// ---------------------------------------------------------------------------
-template <int MMAX, int V, int WHAT, int FLAGS, bool FULL>
-__device__ __forceinline__ uint32_t round_joint_body(const rq_round_args &a,
-                                                     uint32_t g0, int valid,
-                                                     bool in_range) {
-    constexpr bool NTL = (FLAGS & RQ_VAR_NT_LOAD) != 0;
-    constexpr bool NTS = (FLAGS & RQ_VAR_NT_STORE) != 0;
-    constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
-    constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
-    const size_t ld = a.ld;
-    const uint32_t m = a.m;
-    const uint32_t lim = m >= 16 ? 0xFFFFu : ((1u << m) - 1u);
-
-    uint32_t om[V], nm[V], mem[V];
-    uint32_t anymem = 0;
-    if (in_range) {
-        if (a.old_mask) {
-            ld_u16<V, FULL>(a.old_mask + g0, valid, om);
-            ld_u16<V, FULL>(a.new_mask + g0, valid, nm);
-        } else {
-#pragma unroll
-            for (int k = 0; k < V; k++) om[k] = nm[k] = (k < valid) ? lim : 0;
-        }
-    } else {
-#pragma unroll
-        for (int k = 0; k < V; k++) om[k] = nm[k] = 0;
-    }
-#pragma unroll
-    for (int k = 0; k < V; k++) {
-        om[k] &= lim; nm[k] &= lim;
-        mem[k] = om[k] | nm[k];
-        anymem |= mem[k];
-    }
-    // slots no lane of this wave uses are skipped with scalar branches
-    uint32_t wm = 0;
-#pragma unroll
-    for (int p = 0; p < MMAX; p++)
-        if (__ballot((anymem >> p) & 1u) != 0ull) wm |= 1u << p;
-    wm = __builtin_amdgcn_readfirstlane(wm);
-
-    uint32_t st[V];
-#pragma unroll
-    for (int k = 0; k < V; k++) st[k] = 0;
-
-    // ---- vote: slots are processed in chunks of kChunk; a chunk's 3*kChunk plane
-    // loads are all issued before any of them is consumed, and chunk 0 is issued
-    // before the commit side's sort so that it is in flight behind it.
-    constexpr int kChunk = 8;
-    uint32_t el_field = 0;
-    int32_t ct[V], ci[V], mx[V];
-    uint32_t gm[V], sm[V];
-    int32_t cvt[kChunk][V], cvf[kChunk][V], cll[kChunk][V];
-    auto issue_chunk = [&](int c0) {
-#pragma unroll
-        for (int q = 0; q < kChunk; q++) {
-            const int p = c0 + q;
-#pragma unroll
-            for (int k = 0; k < V; k++) { cvt[q][k] = 0; cvf[q][k] = 0; cll[q][k] = 0; }
-            if (p < MMAX && ((wm >> p) & 1u)) {
-                if ((anymem >> p) & 1u) {
-                    ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, cvt[q]);
-                    ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, cvf[q]);
-                    ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, cll[q]);
-                }
-            }
-        }
-    };
-    auto compute_chunk = [&](int c0) {
-#pragma unroll
-        for (int q = 0; q < kChunk; q++) {
-            const int p = c0 + q;
-            if (!(p < MMAX && ((wm >> p) & 1u))) continue;
-            if (!((anymem >> p) & 1u)) continue;
-            int32_t nt[V];
-            bool all_members = true;
-#pragma unroll
-            for (int k = 0; k < V; k++) {
-                const bool member = (mem[k] >> p) & 1u;
-                uint32_t sd, gr, pn;
-                vote_slot(cvt[q][k], cvf[q][k], cll[q][k], ct[k], ci[k], nt[k], sd, gr, pn);
-                if (member) {
-                    gm[k] |= gr << p;
-                    sm[k] |= sd << p;
-                    mx[k] = max(mx[k], nt[k]);
-                    st[k] |= pn ? kStEmptyLog : 0;
-                } else {
-                    nt[k] = cvt[q][k];
-                    if (k < valid) all_members = false;
-                }
-            }
-            if (all_members) {
-                st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
-            } else {
-#pragma unroll
-                for (int k = 0; k < V; k++)
-                    if (k < valid && ((mem[k] >> p) & 1u)) a.voter_term_out[p * ld + g0 + k] = nt[k];
-            }
-        }
-    };
-    if constexpr (DO_VOTE) {
-#pragma unroll
-        for (int k = 0; k < V; k++) { ct[k] = 0; ci[k] = 0; gm[k] = 0; sm[k] = 0; mx[k] = INT_MIN; }
-        if (in_range) {
-            ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
-            ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
-        }
-        issue_chunk(0);
-    }
-
-    int32_t nq[V], gt[V], cm[V], lt[V];
-    bool adv[V], inb[V];
-    if constexpr (DO_COMMIT) {
-        int32_t mt[MMAX][V];
-        int32_t off[V + 1];
-#pragma unroll
-        for (int p = 0; p < MMAX; p++) {
-#pragma unroll
-            for (int k = 0; k < V; k++) mt[p][k] = 0;
-            if ((wm >> p) & 1u) {
-                if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
-            }
-        }
-        int32_t lb[V];
-#pragma unroll
-        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; }
-        off[V] = 0;
-        if (in_range) {
-            ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
-            ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
-            if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
-            const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
-            int32_t o[V];
-            ld_i32<V, NTL, FULL>(offp, valid, o);
-            const int32_t oend = offp[valid];
-#pragma unroll
-            for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
-            off[V] = oend;
-        }
-        // one configuration for the whole wave (the common case) needs one sort
-        bool two_cfgs = false;
-#pragma unroll
-        for (int k = 0; k < V; k++) two_cfgs = two_cfgs || (om[k] != nm[k]);
-        const bool wave_two_cfgs = __ballot(two_cfgs) != 0ull;
-        const bool wave_small = MMAX == 8 || wm < 256u;
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            int32_t no, nn;
-            if (wave_small) {
-                no = masked_quorum<8, MMAX, V>(mt, k, om[k]);
-                nn = wave_two_cfgs ? masked_quorum<8, MMAX, V>(mt, k, nm[k]) : no;
-            } else if constexpr (MMAX == 16) {
-                no = masked_quorum<16, MMAX, V>(mt, k, om[k]);
-                nn = wave_two_cfgs ? masked_quorum<16, MMAX, V>(mt, k, nm[k]) : no;
-            }
-            nq[k] = min(no, nn);
-            const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
-            const uint32_t wi = (uint32_t)nq[k] - (uint32_t)lb[k];
-            adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
-            inb[k] = wi < len;
-            gt[k] = 0;
-            if (adv[k] && inb[k]) gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + wi));
-        }
-    }
-
-    if constexpr (DO_VOTE) {
-        compute_chunk(0);
-        if constexpr (MMAX > kChunk) {
-            if ((wm >> kChunk) != 0u) {          // wave-uniform: some lane has a slot >= kChunk
-                issue_chunk(kChunk);
-                compute_chunk(kChunk);
-            }
-        }
-        uint32_t el[V];
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            const bool maj_old = 2 * __popc(gm[k] & om[k]) > __popc(om[k]);
-            const bool maj_new = 2 * __popc(gm[k] & nm[k]) > __popc(nm[k]);
-            el[k] = maj_old && maj_new && (mx[k] == ct[k]) && mem[k] != 0;
-            if (k < valid) el_field |= el[k] << k;
-        }
-        if (in_range) {
-            st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
-            st_u16<V, NTS, FULL>(a.stepdown_mask + g0, valid, sm);
-            st_u8<V, NTS, FULL>(a.elected + g0, valid, el);
-            st_i32<V, NTS, FULL>(a.max_term + g0, valid, mx);
-        }
-    }
-
-    if constexpr (DO_COMMIT) {
-        int32_t co[V];
-#pragma unroll
-        for (int k = 0; k < V; k++) {
-            co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
-            st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
-        }
-        if (in_range) {
-            st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
-            if (a.commit_lo16) store_commit_lo16<V, NTS, FULL>(a, g0, valid, co);
-        }
-    }
-    if (in_range && a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return el_field;
-}
-
-template <int MMAX, int V, int WHAT, int FLAGS>
-__global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args a) {
-    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-    uint32_t el_field;
-    // Every lane runs a body: the wave-wide ballots inside need all of them.
-    if (g0 + V <= a.G)
-        el_field = round_joint_body<MMAX, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, true);
-    else {
-        const bool in_range = g0 < a.G;
-        el_field = round_joint_body<MMAX, V, WHAT, FLAGS, false>(
-            a, in_range ? (uint32_t)g0 : 0u, in_range ? (int)(a.G - g0) : 0, in_range);
-    }
-    if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
-        if (a.elected_bits) pack_elected<V>(el_field, g0, a.G, a.elected_bits);
-    }
-}
 
 // ---------------------------------------------------------------------------
 // AppendEntries consistency batch: one thread per group; all plane loads of
@@ -769,161 +107,11 @@ __global__ __launch_bounds__(kBlock) void rq_follower_clamp_kernel(
     else st_i32<4, false, false>(out + i0, valid, r);
 }
 
-// ---------------------------------------------------------------------------
-// dispatch
-// ---------------------------------------------------------------------------
-template <int N, int V, int WHAT, int FLAGS>
-hipError_t launch_fixed(const rq_round_args &a, uint32_t block, hipStream_t s) {
-    const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
-    const uint32_t grid = (uint32_t)((threads + block - 1) / block);
-    hipLaunchKernelGGL((rq_round_fixed<N, V, WHAT, FLAGS>), dim3(grid), dim3(block), 0, s, a);
-    return hipGetLastError();
-}
-
-template <int N, int V, int WHAT>
-hipError_t launch_fixed_flags(const rq_round_args &a, int flags, uint32_t block, hipStream_t s) {
-    constexpr int kNt = RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE;
-    constexpr int kNtAll = kNt | RQ_VAR_NT_GATHER;
-    constexpr bool kCommit = (WHAT & RQ_WHAT_COMMIT) != 0;
-    // Builds: every kernel comes as "default policy" and "all non-temporal"
-    // (the gather bit only where there is a gather); the fused round also
-    // has the single-policy builds and the LDS-staged gather as tuning knobs.
-    if constexpr (WHAT != (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) {
-        if ((flags & kNt) != kNt) return launch_fixed<N, V, WHAT, 0>(a, block, s);
-        if constexpr (kCommit)
-            if (flags & RQ_VAR_NT_GATHER) return launch_fixed<N, V, WHAT, kNtAll>(a, block, s);
-        return launch_fixed<N, V, WHAT, kNt>(a, block, s);
-    } else {
-        if constexpr (V == 1)
-            if (flags & RQ_VAR_LDS_LOG) return launch_fixed<N, V, WHAT, kNt | RQ_VAR_LDS_LOG>(a, block, s);
-        if ((flags & kNtAll) == kNtAll) return launch_fixed<N, V, WHAT, kNtAll>(a, block, s);
-        switch (flags & kNt) {
-        case 0: return launch_fixed<N, V, WHAT, 0>(a, block, s);
-        case RQ_VAR_NT_LOAD: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD>(a, block, s);
-        case RQ_VAR_NT_STORE: return launch_fixed<N, V, WHAT, RQ_VAR_NT_STORE>(a, block, s);
-        default: return launch_fixed<N, V, WHAT, kNt>(a, block, s);
-        }
-    }
-}
-
-template <int N, int WHAT>
-hipError_t launch_fixed_v(const rq_round_args &a, int v, int flags, uint32_t block, hipStream_t s) {
-    switch (v) {
-    case 1: return launch_fixed_flags<N, 1, WHAT>(a, flags, block, s);
-    case 2: return launch_fixed_flags<N, 2, WHAT>(a, flags, block, s);
-    default: return launch_fixed_flags<N, 4, WHAT>(a, flags, block, s);
-    }
-}
-
-template <int N>
-hipError_t launch_fixed_what(const rq_round_args &a, int what, int v, int flags, uint32_t block,
-                             hipStream_t s) {
-    switch (what) {
-    case RQ_WHAT_COMMIT: return launch_fixed_v<N, RQ_WHAT_COMMIT>(a, v, flags, block, s);
-    case RQ_WHAT_VOTE: return launch_fixed_v<N, RQ_WHAT_VOTE>(a, v, flags, block, s);
-    default: return launch_fixed_v<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, block, s);
-    }
-}
-
-template <int MMAX, int V, int WHAT, int FLAGS>
-hipError_t launch_joint(const rq_round_args &a, uint32_t block, hipStream_t s) {
-    const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
-    const uint32_t grid = (uint32_t)((threads + block - 1) / block);
-    hipLaunchKernelGGL((rq_round_joint<MMAX, V, WHAT, FLAGS>), dim3(grid), dim3(block), 0, s, a);
-    return hipGetLastError();
-}
-
-template <int MMAX, int V, int WHAT>
-hipError_t launch_joint_flags(const rq_round_args &a, int flags, uint32_t block, hipStream_t s) {
-    constexpr int kNt = RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE;
-    if ((flags & kNt) == kNt) return launch_joint<MMAX, V, WHAT, kNt>(a, block, s);
-    return launch_joint<MMAX, V, WHAT, 0>(a, block, s);
-}
-
-template <int MMAX, int WHAT>
-hipError_t launch_joint_v(const rq_round_args &a, int v, int flags, uint32_t block, hipStream_t s) {
-    switch (v) {
-    case 1: return launch_joint_flags<MMAX, 1, WHAT>(a, flags, block, s);
-    default: return launch_joint_flags<MMAX, 2, WHAT>(a, flags, block, s);
-    }
-}
-
-template <int MMAX>
-hipError_t launch_joint_what(const rq_round_args &a, int what, int v, int flags, uint32_t block,
-                             hipStream_t s) {
-    switch (what) {
-    case RQ_WHAT_COMMIT: return launch_joint_v<MMAX, RQ_WHAT_COMMIT>(a, v, flags, block, s);
-    case RQ_WHAT_VOTE: return launch_joint_v<MMAX, RQ_WHAT_VOTE>(a, v, flags, block, s);
-    default: return launch_joint_v<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, block, s);
-    }
-}
-
-inline bool aligned_to(const void *p, size_t a) {
-    return p == nullptr || (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0;
-}
-
-// Largest V in {4,2,1} not above `want` for which every plane row start
-// (base + p*ld) and every per-group array is aligned for a V-wide access.
-int pick_v(const rq_round_args &a, int want, int what) {
-    for (int v = want; v > 1; v >>= 1) {
-        bool ok = (a.ld % v) == 0;
-        if (what & RQ_WHAT_COMMIT)
-            ok = ok && aligned_to(a.commit_lo16, 2 * v) && aligned_to(a.match, 4 * v) && aligned_to(a.commit, 4 * v) &&
-                 aligned_to(a.leader_term, 4 * v) && aligned_to(a.log_off, 4 * v) && aligned_to(a.log_base, 4 * v) &&
-                 aligned_to(a.commit_out, 4 * v);
-        if (what & RQ_WHAT_VOTE)
-            ok = ok && aligned_to(a.voter_term, 4 * v) && aligned_to(a.voted_for, 4 * v) &&
-                 aligned_to(a.last_log_term, 4 * v) && aligned_to(a.cand_term, 4 * v) &&
-                 aligned_to(a.cand_id, 4 * v) && aligned_to(a.voter_term_out, 4 * v) &&
-                 aligned_to(a.grant_mask, 2 * v) && aligned_to(a.stepdown_mask, 2 * v) &&
-                 aligned_to(a.elected, v) && aligned_to(a.max_term, 4 * v);
-        ok = ok && aligned_to(a.status_out, v) && aligned_to(a.old_mask, 2 * v) &&
-             aligned_to(a.new_mask, 2 * v);
-        if (ok) return v;
-    }
-    return 1;
-}
-
 }  // namespace
 
 hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, int what,
                            int variant, hipStream_t stream) {
-    if (args.G == 0) return hipSuccess;
-    if (args.G > 0x7FFFFFFFu || args.ld < args.G) return hipErrorInvalidValue;
-    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
-    if (variant == 0) variant = joint || n > 9 ? RQ_VAR_DEFAULT_JOINT : RQ_VAR_DEFAULT_FIXED;
-    const rq_round_args &a = args;
-    const int flags = variant & (RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE | RQ_VAR_NT_GATHER | RQ_VAR_LDS_LOG);
-    int want = variant & RQ_VAR_V_MASK;
-    if (want == 0) want = 1;
-    if (want != 1 && want != 2 && want != 4) return hipErrorInvalidValue;
-    const int bsel = (variant >> 8) & 0xF;
-    if (bsel > 4) return hipErrorInvalidValue;
-    const uint32_t block = bsel ? 64u * (uint32_t)bsel : (uint32_t)kBlock;
-
-    if (!joint && n >= 1 && n <= 9) {
-        const int v = pick_v(a, want, what);
-        switch (n) {
-        case 1: return launch_fixed_what<1>(a, what, v, flags, block, stream);
-        case 2: return launch_fixed_what<2>(a, what, v, flags, block, stream);
-        case 3: return launch_fixed_what<3>(a, what, v, flags, block, stream);
-        case 4: return launch_fixed_what<4>(a, what, v, flags, block, stream);
-        case 5: return launch_fixed_what<5>(a, what, v, flags, block, stream);
-        case 6: return launch_fixed_what<6>(a, what, v, flags, block, stream);
-        case 7: return launch_fixed_what<7>(a, what, v, flags, block, stream);
-        case 8: return launch_fixed_what<8>(a, what, v, flags, block, stream);
-        default: return launch_fixed_what<9>(a, what, v, flags, block, stream);
-        }
-    }
-    // per-group membership, or a fixed size beyond the register networks
-    rq_round_args b = a;
-    if (!joint) { b.m = n; b.old_mask = nullptr; b.new_mask = nullptr; }
-    if (b.m < 1 || b.m > 16) return hipErrorInvalidValue;
-    if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
-    if (want > 2) want = 2;
-    const int v = pick_v(b, want, what);
-    if (b.m <= 8) return launch_joint_what<8>(b, what, v, flags, block, stream);
-    return launch_joint_what<16>(b, what, v, flags, block, stream);
+    return launch_round_impl<int32_t>(args, n, joint, what, variant, stream);
 }
 
 hipError_t rq_launch_append_check(const rq_append_args &a, hipStream_t stream) {

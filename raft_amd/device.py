@@ -36,6 +36,8 @@ class DeviceBatch:
         self.device = torch.device(device)
         G, n, ld = self.G, self.n, self.ld
         self.joint = "old_mask" in batch
+        self.wide = np.asarray(batch["match"]).dtype == np.int64    # int64 planes (rq_round64_dev)
+        vdt, tdt = (np.int64, torch.int64) if self.wide else (np.int32, torch.int32)
         host = {}
         for k in self.IN_KEYS:
             if share_log_with is not None and k in ("log_off", "log_term"):
@@ -47,13 +49,13 @@ class DeviceBatch:
                 a = np.zeros(1, a.dtype)
             host[k] = np.ascontiguousarray(a)
         if "log_base" in batch:                 # windowed log arena
-            host["log_base"] = np.ascontiguousarray(batch["log_base"], dtype=np.int32)
+            host["log_base"] = np.ascontiguousarray(batch["log_base"], dtype=vdt)
         if self.joint:
             host["old_mask"] = np.ascontiguousarray(batch["old_mask"].view(np.int16))
             host["new_mask"] = np.ascontiguousarray(batch["new_mask"].view(np.int16))
-        outs = [("commit_out", (G,), torch.int32), ("voter_term_out", (n, ld), torch.int32),
+        outs = [("commit_out", (G,), tdt), ("voter_term_out", (n, ld), tdt),
                 ("grant_mask", (G,), torch.int16), ("stepdown_mask", (G,), torch.int16),
-                ("elected", (G,), torch.uint8), ("max_term", (G,), torch.int32),
+                ("elected", (G,), torch.uint8), ("max_term", (G,), tdt),
                 ("status", (G,), torch.uint8), ("elected_bits", ((G + 63) // 64,), torch.int64)]
         self.t, o = {}, {}
         for k, a in host.items():
@@ -67,7 +69,7 @@ class DeviceBatch:
             o["commit_out"] = self.t["commit"]
             o["voter_term_out"] = self.t["voter_term"]
         if commit_out is not None:
-            assert commit_out.numel() == G and commit_out.dtype == torch.int32
+            assert commit_out.numel() == G and commit_out.dtype == tdt
             o["commit_out"] = commit_out
         if elected_bits is not None:
             assert elected_bits.numel() == (G + 63) // 64 and elected_bits.dtype == torch.int64
@@ -157,6 +159,8 @@ class DeviceEngine:
         """Enqueue one fused round for DeviceBatch b on torch's current stream.
         The argument set is validated once into an rq_plan per (batch, options);
         every later call is a two-argument rq_plan_launch."""
+        if b.wide:
+            return self.round64(b, 3, variant, want_bits, status)
         key = (variant, want_bits, status)
         plan = b._args.get(key)
         if plan is None:
@@ -201,7 +205,28 @@ class DeviceEngine:
         if rc != 0:
             self._check(rc, "rq_fused_round_dev")
 
+    def round64(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """Enqueue the commit (what & 1) and/or vote (what & 2) decision for a wide
+        (int64) DeviceBatch through rq_round64_dev."""
+        assert b.wide
+        t, o = b.t, b.o
+        p = lambda x: None if x is None else x.data_ptr()
+        rc = self._l.rq_round64_dev(
+            self._h, self._stream(), variant, what, b.G, b.n, b.ld,
+            p(t.get("old_mask")), p(t.get("new_mask")),
+            p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
+            p(t.get("log_base")),
+            p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
+            p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
+            p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
+            p(o["elected_bits"]) if want_bits else None,
+            p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]))
+        if rc != 0:
+            self._check(rc, "rq_round64_dev")
+
     def commit_advance(self, b, variant=VAR_DEFAULT):
+        if b.wide:
+            return self.round64(b, 1, variant)
         t, o = b.t, b.o
         p = lambda x: x.data_ptr()
         rc = self._l.rq_commit_advance_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
@@ -212,6 +237,8 @@ class DeviceEngine:
         self._check(rc, "rq_commit_advance_dev")
 
     def vote_tally(self, b, variant=VAR_DEFAULT, want_bits=True):
+        if b.wide:
+            return self.round64(b, 2, variant, want_bits)
         t, o = b.t, b.o
         p = lambda x: x.data_ptr()
         rc = self._l.rq_vote_tally_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,

@@ -14,6 +14,8 @@ from ._lib import RqError, i32p, u8p, u16p, u32p
 ST_LOG_OOB = 0x01
 ST_EMPTY_LOG = 0x02
 LOG_EMPTY = np.iinfo(np.int32).min
+LOG_EMPTY64 = np.iinfo(np.int64).min
+ROUND_COMMIT, ROUND_VOTE = 1, 2
 MAX_SLOTS = 16
 
 
@@ -248,6 +250,62 @@ class QuorumEngine:
                                      pp(mi, i32p), pp(ni, i32p), _p(out["status"], u8p))
         self._check(rc, "rq_append_check")
         return out
+
+    # -- wide layout (int64 planes) -------------------------------------------
+    def round64(self, what=ROUND_COMMIT | ROUND_VOTE, match=None, commit=None, leader_term=None,
+                log_off=None, log_term=None, voter_term=None, voted_for=None, last_log_term=None,
+                cand_term=None, cand_id=None, G=None, old_mask=None, new_mask=None, log_base=None):
+        """rq_round64: the commit and/or vote decision over int64 planes.  Returns a
+        RoundResult whose fields of the side that was not selected are None."""
+        def plane(a, name):
+            a = np.ascontiguousarray(a, dtype=np.int64)
+            if a.ndim != 2:
+                raise ValueError("%s must be a [slots][ld] int64 array" % name)
+            return a
+        first = match if what & ROUND_COMMIT else voter_term
+        n, ld = plane(first, "planes").shape
+        G = ld if G is None else G
+        vp = C.c_void_p
+        ptr = lambda a: None if a is None else vp(a.ctypes.data)
+        keep = []
+
+        def vec(a, dt, name, count):
+            a = _vec(a, dt, name, count); keep.append(a); return a
+        res = RoundResult()
+        for f in RoundResult.__slots__ + VoteResult.__slots__:
+            setattr(res, f, None)
+        ins = [None] * 11
+        outs = [None] * 7
+        res.status = np.zeros(G, np.uint8)
+        if what & ROUND_COMMIT:
+            m = plane(match, "match"); keep.append(m)
+            lt = np.ascontiguousarray(log_term, dtype=np.int64)
+            if lt.size == 0:
+                lt = np.zeros(1, np.int64)
+            keep.append(lt)
+            res.commit = np.zeros(G, np.int64)
+            ins[0:6] = [m, vec(commit, np.int64, "commit", G), vec(leader_term, np.int64, "leader_term", G),
+                        vec(log_off, np.uint32, "log_off", G + 1), lt,
+                        None if log_base is None else vec(log_base, np.int64, "log_base", G)]
+            outs[0] = res.commit
+        if what & ROUND_VOTE:
+            vt, vf, ll = plane(voter_term, "voter_term"), plane(voted_for, "voted_for"), plane(last_log_term, "voter_last_log_term")
+            if not (vt.shape == vf.shape == ll.shape == (n, ld)):
+                raise ValueError("all planes must share one [slots][ld] shape")
+            keep += [vt, vf, ll]
+            ins[6:11] = [vt, vf, ll, vec(cand_term, np.int64, "cand_term", G), vec(cand_id, np.int64, "cand_id", G)]
+            res.voter_term = vt.copy()
+            res.grant_mask = np.zeros(G, np.uint16); res.stepdown_mask = np.zeros(G, np.uint16)
+            res.elected = np.zeros(G, np.uint8); res.max_term = np.zeros(G, np.int64)
+            outs[1:6] = [res.voter_term, res.grant_mask, res.stepdown_mask, res.elected, res.max_term]
+        outs[6] = res.status
+        om = nm = None
+        if old_mask is not None:
+            om, nm = self._masks(old_mask, new_mask, G)
+        rc = self._l.rq_round64(self._h, what, G, n, ld, ptr(om), ptr(nm), *[ptr(a) for a in ins],
+                                *[ptr(a) for a in outs])
+        self._check(rc, "rq_round64")
+        return res
 
     # -- device-resident trio ----------------------------------------------
     def upload(self, match, commit, leader_term, log_off, log_term,

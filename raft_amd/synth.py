@@ -310,3 +310,61 @@ def window_logs(b, keep_committed=0):
     w = Batch(b)
     w["log_off"], w["log_term"], w["log_base"] = new_off, arena.astype(np.int32), base.astype(np.int32)
     return w
+
+
+LOG_EMPTY64 = np.iinfo(np.int64).min
+_WIDE_FIELDS = ("match", "commit", "leader_term", "log_term", "voter_term", "voted_for",
+                "last_log_term", "cand_term", "cand_id", "log_base")
+
+
+def widen(b, index_shift=0, term_shift=0, id_shift=0, seed=DEFAULT_SEED):
+    """The wide-layout (int64) image of a compact batch.  With all shifts 0 it is
+    the same values in 64 bits.  Non-zero shifts move the values out of int32
+    range without changing any decision:
+      index_shift: matchIndex, commitIndex and the log window base of group g
+                   move up by index_shift + (a per-group draw below 2^20) -- the
+                   arena then is a window starting at that base;
+      term_shift:  every term (leader, log, voter, candidate, last-log) moves up
+                   by term_shift, order and equality are preserved;
+      id_shift:    every id except the null id -1 moves up by id_shift.
+    Returns the batch and the per-group index shift (to map results back)."""
+    G = int(b["G"])
+    w = Batch(b)
+    g = np.arange(G, dtype=np.int64)
+    dshift = np.zeros(G, np.int64)
+    if index_shift:
+        dshift[:] = index_shift + _below(seed, F_AUX2, 7 * G + g, 1 << 20)
+    for k in _WIDE_FIELDS:
+        if k in b:
+            w[k] = np.asarray(b[k]).astype(np.int64)
+    if "log_base" not in w and index_shift:
+        w["log_base"] = np.zeros(G, np.int64)
+    if index_shift:
+        w["match"][:, :G] += dshift[None, :]
+        w["commit"][:G] += dshift
+        w["log_base"][:G] += dshift
+    empty = np.asarray(b["last_log_term"]) == LOG_EMPTY
+    for k in ("leader_term", "log_term", "voter_term", "cand_term", "last_log_term"):
+        w[k] = w[k] + term_shift
+    w["last_log_term"] = np.where(empty, LOG_EMPTY64, w["last_log_term"])
+    for k in ("voted_for", "cand_id"):
+        w[k] = np.where(w[k] == -1, -1, w[k] + id_shift)
+    return w, dshift
+
+
+def gen_adversarial64(G, n, seed=DEFAULT_SEED, ld=None):
+    """gen_adversarial in the wide layout, with the int32 extremes replaced by the
+    int64 extremes and a sprinkling of values beyond +-2^40."""
+    b = gen_adversarial(G, n, seed, ld)
+    w, _ = widen(b)
+    lo32, hi32 = np.iinfo(np.int32).min, np.iinfo(np.int32).max
+    lo64, hi64 = np.iinfo(np.int64).min, np.iinfo(np.int64).max
+    for k in ("match", "voter_term", "cand_term", "commit", "leader_term"):
+        a = w[k]
+        a = np.where(a == lo32, lo64, np.where(a == hi32, hi64, a))
+        idx = np.arange(a.size, dtype=np.int64).reshape(a.shape)
+        u = _unit(seed, F_JOINT, idx + 11 * a.size)
+        big = (np.int64(1) << 40) + _below(seed, F_AUX, idx + 13 * a.size, 1000)
+        a = np.where(u < 0.02, big, np.where(u < 0.04, -big, a))
+        w[k] = a
+    return w

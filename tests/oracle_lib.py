@@ -74,6 +74,7 @@ def lib():
         l.orc_follower_clamp.argtypes = [C.c_uint64, i32p, i32p, i32p, i32p]
         l.orc_append_check.argtypes = [u32, u32, u32, u16p, i32p, i32p, i32p, i32p, i32p, u32p, i32p,
                                        i32p, u16p, u16p, i32p, i32p, u8p]
+        l.orc_round64.argtypes = [C.c_int, u32, u32, u32] + [C.c_void_p] * 20
         l.orc_bench_build.argtypes = [u32, u32, u32, i32p, i32p, i32p, u32p, i32p, i32p, i32p, i32p,
                                       i32p, i32p]
         l.orc_bench_build.restype = C.c_void_p
@@ -152,6 +153,36 @@ def fused_round(match, commit, leader_term, log_off, log_term, voter_term, voted
     r = vote_tally(voter_term, voted_for, last_log_term, cand_term, cand_id, G, old_mask, new_mask)
     r["commit"] = c
     r["status"] = r["status"] | st_c
+    return r
+
+
+def round64(what, match=None, commit=None, leader_term=None, log_off=None, log_term=None,
+            voter_term=None, voted_for=None, last_log_term=None, cand_term=None, cand_id=None,
+            G=None, old_mask=None, new_mask=None, log_base=None):
+    """orc_round64: the wide-layout decisions (what: 1 = commit, 2 = vote, 3 = both)."""
+    c64 = lambda a: None if a is None else _c(a, np.int64)
+    first = c64(match if what & 1 else voter_term)
+    n, ld = first.shape; G = ld if G is None else G
+    vp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+    lt = c64(log_term)
+    if lt is not None and lt.size == 0:
+        lt = np.zeros(1, np.int64)
+    ins = [c64(match), c64(commit), c64(leader_term), None if log_off is None else _c(log_off, np.uint32),
+           lt, c64(log_base), c64(voter_term), c64(voted_for), c64(last_log_term), c64(cand_term),
+           c64(cand_id)]
+    r = Result(commit=None, voter_term=None, grant_mask=None, stepdown_mask=None, elected=None,
+               max_term=None, status=np.zeros(G, np.uint8))
+    if what & 1:
+        r["commit"] = np.zeros(G, np.int64)
+    if what & 2:
+        r["voter_term"] = ins[6].copy()
+        r["grant_mask"] = np.zeros(G, np.uint16); r["stepdown_mask"] = np.zeros(G, np.uint16)
+        r["elected"] = np.zeros(G, np.uint8); r["max_term"] = np.zeros(G, np.int64)
+    om = None if old_mask is None else _c(old_mask, np.uint16)
+    nm = None if new_mask is None else _c(new_mask, np.uint16)
+    outs = [r.commit, r.voter_term, r.grant_mask, r.stepdown_mask, r.elected, r.max_term, r.status]
+    rc = lib().orc_round64(what, G, n, ld, vp(om), vp(nm), *[vp(a) for a in ins], *[vp(a) for a in outs])
+    assert rc == 0, rc
     return r
 
 
