@@ -299,9 +299,8 @@ class QuorumEngine:
             res.elected = np.zeros(G, np.uint8); res.max_term = np.zeros(G, np.int64)
             outs[1:6] = [res.voter_term, res.grant_mask, res.stepdown_mask, res.elected, res.max_term]
         outs[6] = res.status
-        om = nm = None
-        if old_mask is not None:
-            om, nm = self._masks(old_mask, new_mask, G)
+        om = None if old_mask is None else _vec(old_mask, np.uint16, "old_mask", G)
+        nm = None if new_mask is None else _vec(new_mask, np.uint16, "new_mask", G)
         rc = self._l.rq_round64(self._h, what, G, n, ld, ptr(om), ptr(nm), *[ptr(a) for a in ins],
                                 *[ptr(a) for a in outs])
         self._check(rc, "rq_round64")
