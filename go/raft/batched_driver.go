@@ -14,20 +14,37 @@ type Group struct {
 	Candidate *Node
 }
 
+// word is the element type of a layout: int32 (compact) or int64 (wide, the
+// full range of Go's int on amd64).
+type word interface{ ~int32 | ~int64 }
+
 // roundBuffers is the structure-of-arrays image of all groups:
 // plane[p*ld+g] for slot p of group g.
-type roundBuffers struct {
+type roundBuffers[T word] struct {
 	groups, slots, ld int
-	match, commit, leaderTerm []int32
+	match, commit, leaderTerm []T
 	logOff                    []uint32
-	logTerm                   []int32
-	voterTerm, votedFor, lastLogTerm, candTerm, candID []int32
-	commitOut, voterTermOut, maxTerm                   []int32
+	logTerm                   []T
+	voterTerm, votedFor, lastLogTerm, candTerm, candID []T
+	commitOut, voterTermOut, maxTerm                   []T
 	grantMask, stepdownMask                            []uint16
 	elected, status                                    []uint8
 }
 
-const logEmpty = math.MinInt32 // RQ_LOG_EMPTY
+// limits of a layout: its largest value, a candidate term no voter reacts to,
+// and the empty-log marker (RQ_LOG_EMPTY / RQ_LOG_EMPTY64), which is the one
+// value of the element type that cannot be stored as a log term.
+type layout[T word] struct {
+	max, belowAll, logEmpty T
+	fits                    func(v int) bool
+}
+
+var compact = layout[int32]{math.MaxInt32, math.MinInt32 + 1, math.MinInt32,
+	func(v int) bool { return v > math.MinInt32 && v <= math.MaxInt32 }}
+var wide = layout[int64]{math.MaxInt64, math.MinInt64, math.MinInt64,
+	func(v int) bool { return true }}
+
+var errRange = errors.New("raft: value outside the range of the engine layout")
 
 // BatchedDriver evaluates one quorum round for every registered group in one
 // GPU launch and applies the decisions to the Go objects.
@@ -35,6 +52,8 @@ type BatchedDriver struct {
 	eng    *rqEngine
 	groups []Group
 	slots  int
+	// LastStepWide reports whether the last Step needed the 64-bit layout.
+	LastStepWide bool
 }
 
 func NewBatchedDriver(device int, groups []Group, slots int, maxLogTerms uint64) (*BatchedDriver, error) {
@@ -45,94 +64,78 @@ func NewBatchedDriver(device int, groups []Group, slots int, maxLogTerms uint64)
 	return &BatchedDriver{eng: eng, groups: groups, slots: slots}, nil
 }
 
-func narrow(v int) (int32, error) {
-	if v < math.MinInt32+1 || v > math.MaxInt32 {
-		return 0, errors.New("raft: value outside the int32 range of the batched engine")
-	}
-	return int32(v), nil
-}
-
-// flatten builds the SoA image. A group without a leader gets commit =
-// MaxInt32 (N > commit is never true); a group without a candidate gets
-// candTerm = MinInt32+1 (below every term: no step-down, no grant).
-func (d *BatchedDriver) flatten() (*roundBuffers, error) {
+// flatten builds the SoA image in layout L. A group without a leader gets
+// commit = the layout's maximum (N > commit is never true); a group without a
+// candidate gets the layout's belowAll term (no voter's term moves and the
+// vote outputs of such a group are not applied).
+func flatten[T word](d *BatchedDriver, L layout[T]) (*roundBuffers[T], error) {
 	G, n := len(d.groups), d.slots
-	b := &roundBuffers{groups: G, slots: n, ld: G}
-	plane := func() []int32 { return make([]int32, n*G) }
+	b := &roundBuffers[T]{groups: G, slots: n, ld: G}
+	plane := func() []T { return make([]T, n*G) }
 	b.match, b.voterTerm, b.votedFor, b.lastLogTerm, b.voterTermOut = plane(), plane(), plane(), plane(), plane()
-	vec := func() []int32 { return make([]int32, G) }
+	vec := func() []T { return make([]T, G) }
 	b.commit, b.leaderTerm, b.candTerm, b.candID, b.commitOut, b.maxTerm = vec(), vec(), vec(), vec(), vec(), vec()
 	b.grantMask, b.stepdownMask = make([]uint16, G), make([]uint16, G)
 	b.elected, b.status = make([]uint8, G), make([]uint8, G)
 	b.logOff = make([]uint32, G+1)
-	var err error
+	put := func(dst *T, v int) bool {
+		if !L.fits(v) {
+			return false
+		}
+		*dst = T(v)
+		return true
+	}
 	for g, grp := range d.groups {
 		if len(grp.Members) != n {
 			return nil, errors.New("raft: group size differs from the driver's slot count")
 		}
-		b.commit[g], b.candTerm[g] = math.MaxInt32, math.MinInt32+1
+		b.commit[g], b.candTerm[g] = L.max, L.belowAll
 		if l := grp.Leader; l != nil {
-			if b.commit[g], err = narrow(l.commitIndex); err != nil {
-				return nil, err
-			}
-			if b.leaderTerm[g], err = narrow(l.currentTerm); err != nil {
-				return nil, err
+			if !put(&b.commit[g], l.commitIndex) || !put(&b.leaderTerm[g], l.currentTerm) {
+				return nil, errRange
 			}
 			for p := 0; p < n && p < len(l.matchIndex); p++ {
-				if b.match[p*G+g], err = narrow(l.matchIndex[p]); err != nil {
-					return nil, err
+				if !put(&b.match[p*G+g], l.matchIndex[p]) {
+					return nil, errRange
 				}
 			}
 			for _, e := range l.log {
-				t, err := narrow(e.TermNum)
-				if err != nil {
-					return nil, err
+				var t T
+				if !put(&t, e.TermNum) {
+					return nil, errRange
 				}
 				b.logTerm = append(b.logTerm, t)
 			}
 		}
 		b.logOff[g+1] = uint32(len(b.logTerm))
 		if c := grp.Candidate; c != nil {
-			if b.candTerm[g], err = narrow(c.currentTerm); err != nil {
-				return nil, err
-			}
-			if b.candID[g], err = narrow(c.id); err != nil {
-				return nil, err
+			if !put(&b.candTerm[g], c.currentTerm) || !put(&b.candID[g], c.id) {
+				return nil, errRange
 			}
 		}
 		for p, m := range grp.Members {
 			i := p*G + g
-			if b.voterTerm[i], err = narrow(m.currentTerm); err != nil {
-				return nil, err
+			if !put(&b.voterTerm[i], m.currentTerm) || !put(&b.votedFor[i], m.votedFor) {
+				return nil, errRange
 			}
-			if b.votedFor[i], err = narrow(m.votedFor); err != nil {
-				return nil, err
-			}
-			b.lastLogTerm[i] = logEmpty
+			b.lastLogTerm[i] = L.logEmpty
 			if len(m.log) > 0 {
-				if b.lastLogTerm[i], err = narrow(m.log[len(m.log)-1].TermNum); err != nil {
-					return nil, err
+				if !put(&b.lastLogTerm[i], m.log[len(m.log)-1].TermNum) || b.lastLogTerm[i] == L.logEmpty {
+					return nil, errRange
 				}
 			}
 		}
 	}
 	if len(b.logTerm) == 0 {
-		b.logTerm = []int32{0}
+		b.logTerm = []T{0}
 	}
 	return b, nil
 }
 
-// Step runs one fused round and applies it: voters' terms and roles
+// apply writes one round's decisions back: voters' terms and roles
 // (raft.go:219-221), the leader's commitIndex, and BecomeLeader for every
 // candidate that won.
-func (d *BatchedDriver) Step() error {
-	b, err := d.flatten()
-	if err != nil {
-		return err
-	}
-	if err := d.eng.fusedRound(b); err != nil {
-		return err
-	}
+func apply[T word](d *BatchedDriver, b *roundBuffers[T]) {
 	G := b.groups
 	for g, grp := range d.groups {
 		if grp.Candidate != nil {
@@ -151,6 +154,32 @@ func (d *BatchedDriver) Step() error {
 			grp.Leader.commitIndex = int(b.commitOut[g])
 		}
 	}
+}
+
+// Step runs one fused round and applies it. The compact layout is tried first;
+// if some value does not fit int32 the round runs in the wide layout.
+func (d *BatchedDriver) Step() error {
+	b, err := flatten(d, compact)
+	if err == errRange {
+		w, err := flatten(d, wide)
+		if err != nil {
+			return err
+		}
+		if err := d.eng.round64(w); err != nil {
+			return err
+		}
+		apply(d, w)
+		d.LastStepWide = true
+		return nil
+	}
+	if err != nil {
+		return err
+	}
+	if err := d.eng.fusedRound(b); err != nil {
+		return err
+	}
+	apply(d, b)
+	d.LastStepWide = false
 	return nil
 }
 

@@ -91,36 +91,51 @@ void Node::SeedLogForTest(const std::vector<int64_t> &terms) {
 
 // ---- batched driver ---------------------------------------------------------
 
+// The lowest value of each layout is its empty-log marker and cannot be a value.
 static bool narrow(int64_t v, int32_t &out) {
-    if (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX) return false;  // INT32_MIN is RQ_LOG_EMPTY
+    if (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX) return false;
     out = (int32_t)v;
     return true;
 }
+static bool narrow(int64_t v, int64_t &out) {
+    out = v;
+    return true;
+}
 
-int BatchedDriver::Flatten(RoundBuffers &b) const {
-    const uint32_t G = (uint32_t)groups_.size(), n = slots_;
-    b = RoundBuffers();
+template <typename T> struct layout_limits;
+template <> struct layout_limits<int32_t> {
+    static constexpr int32_t kMax = INT32_MAX, kBelowAll = INT32_MIN + 1, kLogEmpty = RQ_LOG_EMPTY;
+};
+template <> struct layout_limits<int64_t> {
+    static constexpr int64_t kMax = INT64_MAX, kBelowAll = INT64_MIN, kLogEmpty = RQ_LOG_EMPTY64;
+};
+
+template <typename T>
+int BatchedDriver::FlattenT(const std::vector<Group> &groups, uint32_t n, RoundBuffersT<T> &b) {
+    typedef layout_limits<T> lim;
+    const uint32_t G = (uint32_t)groups.size();
+    b = RoundBuffersT<T>();
     b.groups = G; b.slots = n; b.ld = G;
     const size_t plane = (size_t)n * G;
     b.match.assign(plane, 0); b.voterTerm.assign(plane, 0); b.votedFor.assign(plane, -1);
-    b.lastLogTerm.assign(plane, RQ_LOG_EMPTY); b.voterTermOut.assign(plane, 0);
-    b.commit.assign(G, INT32_MAX);          // no leader: N > commit is never true
+    b.lastLogTerm.assign(plane, lim::kLogEmpty); b.voterTermOut.assign(plane, 0);
+    b.commit.assign(G, lim::kMax);          // no leader: N > commit is never true
     b.leaderTerm.assign(G, 0);
-    b.candTerm.assign(G, INT32_MIN + 1);    // no candidate: below every term, nobody reacts
+    b.candTerm.assign(G, lim::kBelowAll);   // no candidate: no voter's term moves, results are not applied
     b.candId.assign(G, -1);
     b.commitOut.assign(G, 0); b.maxTerm.assign(G, 0);
     b.grantMask.assign(G, 0); b.stepdownMask.assign(G, 0);
     b.elected.assign(G, 0); b.status.assign(G, 0);
     b.logOff.assign((size_t)G + 1, 0);
     for (uint32_t g = 0; g < G; g++) {
-        const Group &grp = groups_[g];
+        const Group &grp = groups[g];
         if (grp.Members.size() != n) return kDriverShape;
         if (const Node *l = grp.Leader) {
             if (!narrow(l->commitIndex, b.commit[g]) || !narrow(l->currentTerm, b.leaderTerm[g])) return kDriverRange;
             for (uint32_t p = 0; p < n && p < l->matchIndex.size(); p++)
                 if (!narrow(l->matchIndex[p], b.match[(size_t)p * G + g])) return kDriverRange;
             for (const Entry &e : l->log) {
-                int32_t t;
+                T t;
                 if (!narrow(e.TermNum, t)) return kDriverRange;
                 b.logTerm.push_back(t);
             }
@@ -134,17 +149,21 @@ int BatchedDriver::Flatten(RoundBuffers &b) const {
             const Node *m = grp.Members[p];
             const size_t i = (size_t)p * G + g;
             if (!narrow(m->currentTerm, b.voterTerm[i]) || !narrow(m->votedFor, b.votedFor[i])) return kDriverRange;
-            if (!m->log.empty() && !narrow(m->log.back().TermNum, b.lastLogTerm[i])) return kDriverRange;
+            if (!m->log.empty()) {
+                if (!narrow(m->log.back().TermNum, b.lastLogTerm[i]) || b.lastLogTerm[i] == lim::kLogEmpty)
+                    return kDriverRange;
+            }
         }
     }
     if (b.logTerm.empty()) b.logTerm.push_back(0);
     return kDriverOk;
 }
 
-void BatchedDriver::Apply(const RoundBuffers &b) {
+template <typename T>
+void BatchedDriver::ApplyT(std::vector<Group> &groups, const RoundBuffersT<T> &b) {
     const uint32_t G = b.groups;
     for (uint32_t g = 0; g < G; g++) {
-        Group &grp = groups_[g];
+        Group &grp = groups[g];
         Node *leader_before = grp.Leader;
         if (grp.Candidate) {
             for (uint32_t p = 0; p < b.slots; p++) {
@@ -162,26 +181,53 @@ void BatchedDriver::Apply(const RoundBuffers &b) {
     }
 }
 
+int BatchedDriver::Flatten(RoundBuffers &b) const { return FlattenT(groups_, slots_, b); }
+int BatchedDriver::Flatten(RoundBuffers64 &b) const { return FlattenT(groups_, slots_, b); }
+void BatchedDriver::Apply(const RoundBuffers &b) { ApplyT(groups_, b); }
+void BatchedDriver::Apply(const RoundBuffers64 &b) { ApplyT(groups_, b); }
+
 BatchedDriver::~BatchedDriver() {
     if (engine_) rq_engine_destroy(engine_);
 }
 
-int BatchedDriver::Step(int device) {
-    RoundBuffers b;
-    int rc = Flatten(b);
-    if (rc != kDriverOk) return rc == kDriverRange ? RQ_E_RANGE : RQ_E_ARG;
-    const uint64_t need = b.logTerm.size();
-    if (engine_ && (engine_device_ != device || need > engine_log_cap_ || b.groups > engine_groups_)) {
+int BatchedDriver::EnsureEngine(int device, uint32_t groups, uint32_t slots, uint64_t need) {
+    if (engine_ && (engine_device_ != device || need > engine_log_cap_ || groups > engine_groups_)) {
         rq_engine_destroy(engine_);
         engine_ = nullptr;
     }
     if (!engine_) {
         engine_log_cap_ = need * 2 + 4096;              // room for the leaders' logs to grow
-        engine_groups_ = b.groups ? b.groups : 1;
-        rc = rq_engine_create(device, engine_groups_, b.slots, engine_log_cap_, &engine_);
+        engine_groups_ = groups ? groups : 1;
+        int rc = rq_engine_create(device, engine_groups_, slots, engine_log_cap_, &engine_);
         if (rc != RQ_OK) { engine_ = nullptr; return rc; }
         engine_device_ = device;
     }
+    return RQ_OK;
+}
+
+int BatchedDriver::Step(int device) {
+    RoundBuffers b;
+    int rc = Flatten(b);
+    if (rc == kDriverRange) {               // some value needs more than 32 bits: wide layout
+        RoundBuffers64 w;
+        rc = Flatten(w);
+        if (rc != kDriverOk) return rc == kDriverRange ? RQ_E_RANGE : RQ_E_ARG;
+        rc = EnsureEngine(device, w.groups, w.slots, w.logTerm.size());
+        if (rc != RQ_OK) return rc;
+        rc = rq_round64(engine_, RQ_ROUND_COMMIT | RQ_ROUND_VOTE, w.groups, w.slots, w.ld, nullptr, nullptr,
+                        w.match.data(), w.commit.data(), w.leaderTerm.data(), w.logOff.data(),
+                        w.logTerm.data(), nullptr, w.voterTerm.data(), w.votedFor.data(),
+                        w.lastLogTerm.data(), w.candTerm.data(), w.candId.data(), w.commitOut.data(),
+                        w.voterTermOut.data(), w.grantMask.data(), w.stepdownMask.data(),
+                        w.elected.data(), w.maxTerm.data(), w.status.data());
+        if (rc != RQ_OK) return rc;
+        Apply(w);
+        last_step_wide_ = true;
+        return RQ_OK;
+    }
+    if (rc != kDriverOk) return RQ_E_ARG;
+    rc = EnsureEngine(device, b.groups, b.slots, b.logTerm.size());
+    if (rc != RQ_OK) return rc;
     rc = rq_fused_round(engine_, b.groups, b.slots, b.ld, b.match.data(), b.commit.data(),
                         b.leaderTerm.data(), b.logOff.data(), b.logTerm.data(), b.voterTerm.data(),
                         b.votedFor.data(), b.lastLogTerm.data(), b.candTerm.data(), b.candId.data(),
@@ -189,6 +235,7 @@ int BatchedDriver::Step(int device) {
                         b.stepdownMask.data(), b.elected.data(), b.maxTerm.data(), b.status.data());
     if (rc != RQ_OK) return rc;
     Apply(b);
+    last_step_wide_ = false;
     return RQ_OK;
 }
 

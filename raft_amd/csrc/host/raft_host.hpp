@@ -92,16 +92,20 @@ struct Group {
     Node *Candidate = nullptr;    // member currently asking for votes, or null
 };
 
-// Structure-of-arrays image of all groups, layout of include/rq.h.
-struct RoundBuffers {
+// Structure-of-arrays image of all groups, layout of include/rq.h: T = int32_t
+// is the compact layout, T = int64_t the wide one (rq_round64).
+template <typename T>
+struct RoundBuffersT {
     uint32_t groups = 0, slots = 0, ld = 0;
-    std::vector<int32_t> match, commit, leaderTerm, logTerm;
+    std::vector<T> match, commit, leaderTerm, logTerm;
     std::vector<uint32_t> logOff;
-    std::vector<int32_t> voterTerm, votedFor, lastLogTerm, candTerm, candId;
-    std::vector<int32_t> commitOut, voterTermOut, maxTerm;
+    std::vector<T> voterTerm, votedFor, lastLogTerm, candTerm, candId;
+    std::vector<T> commitOut, voterTermOut, maxTerm;
     std::vector<uint16_t> grantMask, stepdownMask;
     std::vector<uint8_t> elected, status;
 };
+typedef RoundBuffersT<int32_t> RoundBuffers;
+typedef RoundBuffersT<int64_t> RoundBuffers64;
 
 enum : int { kDriverOk = 0, kDriverRange = -2, kDriverShape = -1 };
 
@@ -109,22 +113,33 @@ class BatchedDriver {
 public:
     BatchedDriver(std::vector<Group> groups, uint32_t slots) : groups_(std::move(groups)), slots_(slots) {}
     ~BatchedDriver();
-    // AoS -> SoA.  Values outside int32 give kDriverRange and leave `b` unspecified.
+    // AoS -> SoA.  A value the layout cannot hold gives kDriverRange and leaves
+    // `b` unspecified: outside int32 for the compact layout; for the wide layout
+    // only a log term equal to INT64_MIN (the empty-log marker).
     int Flatten(RoundBuffers &b) const;
+    int Flatten(RoundBuffers64 &b) const;
     // Applies one round's outputs to the objects: voter terms and roles
     // (raft.go:219-221), leader commitIndex, BecomeLeader for winners.
     void Apply(const RoundBuffers &b);
-    // Flatten -> rq_fused_round on `device` -> Apply.  Returns an RQ_* code.
+    void Apply(const RoundBuffers64 &b);
+    // Flatten -> one fused round on `device` -> Apply.  The compact layout is
+    // tried first; if some value does not fit int32 the round runs in the wide
+    // layout instead.  Returns an RQ_* code.
     int Step(int device);
+    bool LastStepWide() const { return last_step_wide_; }
     std::vector<Group> &Groups() { return groups_; }
 
 private:
+    int EnsureEngine(int device, uint32_t groups, uint32_t slots, uint64_t log_terms);
+    template <typename T> static int FlattenT(const std::vector<Group> &groups, uint32_t n, RoundBuffersT<T> &b);
+    template <typename T> static void ApplyT(std::vector<Group> &groups, const RoundBuffersT<T> &b);
     std::vector<Group> groups_;
     uint32_t slots_;
     rq_engine *engine_ = nullptr;
     int engine_device_ = -1;
     uint64_t engine_log_cap_ = 0;
     uint32_t engine_groups_ = 0;
+    bool last_step_wide_ = false;
 };
 
 }  // namespace raft

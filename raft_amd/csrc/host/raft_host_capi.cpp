@@ -157,5 +157,28 @@ void rh_driver_apply(rh_cluster *c, const int32_t *commit_out, const int32_t *vo
 
 // Flatten -> rq_fused_round on the GPU -> Apply.  Returns an RQ_* code.
 int rh_driver_step(rh_cluster *c, int device) { return c->driver->Step(device); }
+// 1 if the last successful step had to use the wide (int64) layout
+int rh_driver_last_step_wide(rh_cluster *c) { return c->driver->LastStepWide() ? 1 : 0; }
+
+// Wide-layout Flatten: returns the driver code and the number of log terms; copies nothing
+// when an output pointer is null.  Planes are [n][G] int64.
+int rh_driver_flatten64(rh_cluster *c, int64_t *match, int64_t *commit, int64_t *leader_term,
+                        uint32_t *log_off, int64_t *log_term, uint64_t log_term_cap,
+                        int64_t *voter_term, int64_t *voted_for, int64_t *last_log_term,
+                        int64_t *cand_term, int64_t *cand_id, uint64_t *log_terms_used) {
+    RoundBuffers64 b;
+    int rc = c->driver->Flatten(b);
+    if (rc != 0) return rc;
+    const size_t plane = (size_t)b.slots * b.groups * 8, vec = (size_t)b.groups * 8;
+    std::memcpy(match, b.match.data(), plane); std::memcpy(voter_term, b.voterTerm.data(), plane);
+    std::memcpy(voted_for, b.votedFor.data(), plane); std::memcpy(last_log_term, b.lastLogTerm.data(), plane);
+    std::memcpy(commit, b.commit.data(), vec); std::memcpy(leader_term, b.leaderTerm.data(), vec);
+    std::memcpy(cand_term, b.candTerm.data(), vec); std::memcpy(cand_id, b.candId.data(), vec);
+    std::memcpy(log_off, b.logOff.data(), ((size_t)b.groups + 1) * 4);
+    *log_terms_used = b.logTerm.size();
+    if (b.logTerm.size() > log_term_cap) return -3;
+    std::memcpy(log_term, b.logTerm.data(), b.logTerm.size() * 8);
+    return 0;
+}
 
 }  // extern "C"

@@ -42,6 +42,9 @@ def lib():
         l.rh_driver_apply.argtypes = [C.c_void_p, i32p, i32p, u16p, u16p, u8p, i32p]
         l.rh_driver_apply.restype = None
         l.rh_driver_step.argtypes = [C.c_void_p, C.c_int]
+        l.rh_driver_last_step_wide.argtypes = [C.c_void_p]
+        l.rh_driver_flatten64.argtypes = [C.c_void_p, i64p, i64p, i64p, u32p, i64p, C.c_uint64,
+                                          i64p, i64p, i64p, i64p, i64p, C.POINTER(C.c_uint64)]
         _l = l
     return _l
 
@@ -119,6 +122,27 @@ class Cluster:
                                       p(b["cand_id"], i32p), C.byref(used))
         b["log_term"] = b["log_term"][: used.value]
         return rc, b
+
+    def flatten64(self, log_cap=1 << 20):
+        """The wide-layout image of the objects (int64 planes)."""
+        G, n = self.G, self.n
+        plane = lambda: np.zeros((n, G), np.int64)
+        vec = lambda: np.zeros(G, np.int64)
+        b = dict(match=plane(), commit=vec(), leader_term=vec(), log_off=np.zeros(G + 1, np.uint32),
+                 log_term=np.zeros(log_cap, np.int64), voter_term=plane(), voted_for=plane(),
+                 last_log_term=plane(), cand_term=vec(), cand_id=vec())
+        used = C.c_uint64()
+        p = lambda a, t: a.ctypes.data_as(t)
+        rc = self.l.rh_driver_flatten64(self.h, p(b["match"], i64p), p(b["commit"], i64p), p(b["leader_term"], i64p),
+                                        p(b["log_off"], u32p), p(b["log_term"], i64p), log_cap,
+                                        p(b["voter_term"], i64p), p(b["voted_for"], i64p),
+                                        p(b["last_log_term"], i64p), p(b["cand_term"], i64p),
+                                        p(b["cand_id"], i64p), C.byref(used))
+        b["log_term"] = b["log_term"][: used.value]
+        return rc, b
+
+    def last_step_wide(self):
+        return bool(self.l.rh_driver_last_step_wide(self.h))
 
     def apply(self, r):
         p = lambda a, dt, t: np.ascontiguousarray(a, dtype=dt).ctypes.data_as(t)

@@ -77,10 +77,26 @@ def test_append_entries_kats(k):
         c.close()
 
 
-def _build(G, n, seed):
-    """A cluster whose object state equals a synthetic batch; returns (cluster, batch)."""
+def _build(G, n, seed, term_shift=0):
+    """A cluster whose object state equals a synthetic batch (every term moved up
+    by term_shift); returns (cluster, batch) -- the batch is returned unshifted."""
     b = synth.gen_fused(G, n, seed=seed)
     c = h.Cluster(G, n)
+    if term_shift:
+        c0, b0 = c, b
+        b = synth.Batch(b0)
+        for k in ("voter_term", "last_log_term", "log_term", "leader_term", "cand_term"):
+            b[k] = b0[k].astype(np.int64) + term_shift
+        _seed_objects(c, b, n, G)
+        # the unshifted planes must describe the objects too (see the end of _seed_objects)
+        for k in ("voter_term", "last_log_term"):
+            b0[k] = (b[k] - term_shift).astype(np.int32)
+        return c, b0
+    _seed_objects(c, b, n, G)
+    return c, b
+
+
+def _seed_objects(c, b, n, G):
     for g in range(G):
         lead = int(b.cand_id[g] + 1) % n                       # some member other than the candidate leads
         lo, hi = int(b.log_off[g]), int(b.log_off[g + 1])
@@ -100,7 +116,6 @@ def _build(G, n, seed):
         b.voter_term[lead, g] = b.leader_term[g]
         b.last_log_term[lead, g] = b.log_term[hi - 1]
         b.voter_term[cand, g] = b.cand_term[g]
-    return c, b
 
 
 def test_flatten_matches_the_objects_and_apply_matches_the_oracle():
@@ -175,5 +190,42 @@ def test_step_on_gpu_equals_per_node_reference_calls():
             assert c.get(g, lead)["commitIndex"] == r.commit[g]
             assert (c.get_roles(g)[0] == cand) == bool(r.elected[g])
         assert c.step(0) == 0                      # a second round on the applied state
+    finally:
+        c.close()
+
+
+def test_values_beyond_int32_need_the_wide_flatten():
+    SH = 1 << 40
+    c, b = _build(50, 3, seed=5, term_shift=SH)
+    try:
+        rc, _ = c.flatten()
+        assert rc == -2                                   # the compact layout cannot hold these terms
+        rc, f = c.flatten64()
+        assert rc == 0
+        assert np.array_equal(f["voter_term"], b.voter_term.astype(np.int64) + SH)
+        assert np.array_equal(f["last_log_term"], b.last_log_term.astype(np.int64) + SH)
+        assert np.array_equal(f["cand_term"], b.cand_term.astype(np.int64) + SH)
+        assert np.array_equal(f["leader_term"], b.leader_term.astype(np.int64) + SH)
+        assert np.array_equal(f["log_term"], b.log_term.astype(np.int64) + SH)
+        assert np.array_equal(f["match"], b.match) and np.array_equal(f["voted_for"], b.voted_for)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_step_falls_back_to_the_wide_layout():
+    """Terms beyond int32: Step() runs rq_round64 and applies the same decisions the
+    compact round gives on the unshifted state."""
+    G, n, SH = 2000, 5, 1 << 40
+    c, b = _build(G, n, seed=29, term_shift=SH)
+    try:
+        r = o.fused_round(*b.fused_args())
+        assert c.step(0) == 0 and c.last_step_wide()
+        for g in range(G):
+            lead, cand = int(b.cand_id[g] + 1) % n, int(b.cand_id[g])
+            for p in range(n):
+                assert c.get(g, p)["currentTerm"] == int(r.voter_term[p, g]) + SH
+            assert c.get(g, lead)["commitIndex"] == r.commit[g]
+            assert (c.get_roles(g)[0] == cand) == bool(r.elected[g])
     finally:
         c.close()
