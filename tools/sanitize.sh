@@ -14,5 +14,5 @@ trap restore EXIT
 gcc $SAN -std=c11 -fPIC -shared -pthread oracle/raft_oracle.c -o oracle/librq_oracle.so
 g++ $SAN -std=c++17 -fPIC -shared raft_amd/csrc/host/raft_host.cpp raft_amd/csrc/host/raft_host_capi.cpp \
     -Lraft_amd -lrq -Wl,-rpath,'$ORIGIN' -o raft_amd/libraft_host.so
-LD_PRELOAD="$PRE" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
-    python -m pytest tests/test_oracle_kats.py tests/test_host_cpp.py -x -q -m "not gpu"
+LD_PRELOAD="$PRE${LD_PRELOAD:+ $LD_PRELOAD}" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
+    python -m pytest tests/test_oracle_kats.py tests/test_host_cpp.py tests/test_wide_layout.py -x -q -m "not gpu"
