@@ -51,8 +51,10 @@ def parse():
     ap.add_argument("--ld-pad", type=int, default=256,
                     help="plane stride = groups + pad (elements): keeps the slot planes off one power-of-two stride")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
-    ap.add_argument("--summary", choices=["u16", "i32"], default="u16",
-                    help="commit summary on the wire: 16-bit window with escape (default) or full int32")
+    ap.add_argument("--summary", choices=["u4", "u8", "u16", "i32"], default="u4",
+                    help="commit summary on the wire: u4/u8 = the round's commitIndex advance in 4/8 bits "
+                         "(offset from the input commitIndex, all ones = escape), u16 = 16-bit offset from 0, "
+                         "i32 = the full vector")
     ap.add_argument("--rounds-per-exchange", type=int, default=4,
                     help="summaries of this many consecutive rounds travel in one all-gather")
     ap.add_argument("--exchange-impl", choices=["auto", "native", "torch"], default="torch",
@@ -150,7 +152,7 @@ def main():
             first_mixed = first_mixed or b
         if args.layout == "i64":
             if args.workload == "mixed" or (ex is not None and args.summary == "i32"):
-                raise SystemExit("--layout i64 runs the fused workload with the u16 summary")
+                raise SystemExit("--layout i64 runs the fused workload with a narrow (u4, u8, u16) summary")
             # indices can only leave the int32 range together with a window base
             b, _ = synth.widen(b, index_shift=(1 << 40) if args.log_window >= 0 else 0,
                                term_shift=1 << 41, id_shift=1 << 42, seed=seed)
@@ -161,7 +163,8 @@ def main():
             kw.update(commit_out=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R))
         elif ex is not None:
             kw.update(commit_lo16=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R),
-                      summary_escapes=escape_counter)
+                      summary_escapes=escape_counter, summary_bits=ex.bits,
+                      summary_base="commit" if ex.bits < 16 else None)
         sets.append(DeviceBatch(b, device, **kw))
     if args.workload == "fused":
         bytes_per_group = alg_bytes_per_group(n, args.what, args.layout)

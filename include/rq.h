@@ -75,6 +75,8 @@ int rq_engine_create(int device, uint32_t max_groups, uint32_t max_slots,
                      uint64_t max_log_terms, rq_engine **out);
 int rq_engine_destroy(rq_engine *e);
 int rq_last_hip_error(const rq_engine *e);      /* last hipError_t seen       */
+int rq_engine_set_summary_width(rq_engine *e, int bits); /* 16 (default), 8 or 4; see
+                                                   the device-pointer section  */
 int rq_engine_device(const rq_engine *e);
 
 /* ---- synchronous entry points on caller (host) buffers ------------------ */
@@ -233,6 +235,15 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  * the escape value 65535, in which case *summary_escapes (if not NULL) is
  * incremented and the receiver must fetch the full commit vector; the host
  * moves summary_base forward before offsets reach the window's end.
+ * rq_engine_set_summary_width narrows the summary further for launches and
+ * plans made afterwards on that engine: 8 = one byte per group (escape 255),
+ * 4 = sixteen groups per 64-bit word, group g in bits 4*(g%16) of word g/16
+ * (escape 15; the buffer is then ceil(G/16) words, 8-byte aligned); the buffer
+ * is still passed as commit_lo16.  summary_base may be the round's own input
+ * commit plane: the summary is then the round's advance, which a receiver adds
+ * to the commitIndex it already holds (xGMI links are point-to-point, so the
+ * bytes per group on the wire decide how far the exchange of a 30 us round
+ * scales).
  * log_base, if not NULL, makes the log arena a window: slot i of group g's
  * arena slice holds log[log_base[g] + i], so a host may keep only the
  * uncommitted suffix of every log on the device (entries at or below

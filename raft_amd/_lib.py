@@ -32,6 +32,7 @@ PROTOTYPES = {
     "rq_engine_destroy": [vp],
     "rq_last_hip_error": [vp],
     "rq_engine_device": [vp],
+    "rq_engine_set_summary_width": [vp, cint],
     "rq_commit_advance": [vp, u32, u32, u32] + _COMMIT_IN + [i32p, u8p],
     "rq_vote_tally": [vp, u32, u32, u32] + _VOTE_IN + _VOTE_OUT + [u8p],
     "rq_fused_round": [vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN + [i32p] + _VOTE_OUT + [u8p],

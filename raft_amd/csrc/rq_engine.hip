@@ -24,6 +24,7 @@ struct rq_engine {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::atomic<int> last_hip{0};
+    std::atomic<uint32_t> summary_bits{16};   // width of the narrow commit summary (device launches)
     char *slab = nullptr;
     char *slab64 = nullptr;   // staging of the 64-bit host-buffer entry points (made on first use)
     // planes [max_slots][ld]
@@ -283,7 +284,9 @@ int dev_launch(rq_engine *e, void *stream, int variant, uint32_t n, bool joint, 
             return RQ_E_ARG;
     if (joint && (!a.old_mask || !a.new_mask)) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = rq_launch_round(a, n, joint, what, variant, (hipStream_t)stream);
+    rq_round_args_t<T> b = a;
+    b.summary_bits = e->summary_bits.load();
+    hipError_t err = rq_launch_round(b, n, joint, what, variant, (hipStream_t)stream);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;
@@ -386,6 +389,12 @@ int rq_engine_destroy(rq_engine *e) {
     }
     delete e;
     return rc;
+}
+
+int rq_engine_set_summary_width(rq_engine *e, int bits) {
+    if (!e || (bits != 16 && bits != 8 && bits != 4)) return RQ_E_ARG;
+    e->summary_bits.store((uint32_t)bits);
+    return RQ_OK;
 }
 
 int rq_last_hip_error(const rq_engine *e) { return e ? e->last_hip.load() : 0; }
@@ -909,6 +918,7 @@ int rq_plan_fused_round(rq_engine *e, int variant, int joint, uint32_t G, uint32
     a.status_out = status_out; a.elected_bits = elected_bits;
     a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
     a.log_base = log_base;
+    a.summary_bits = e->summary_bits.load();
     if (n < 1 || n > RQ_MAX_SLOTS || ld < G || G > 0x7FFFFFFFu) return RQ_E_ARG;
     if (!match || !commit || !leader_term || !log_off || !log_term || !commit_out || !voter_term ||
         !voted_for || !voter_last_log_term || !cand_term || !cand_id || !voter_term_out ||

@@ -38,11 +38,14 @@ struct rq_round_args_t {
     T *max_term;
     uint8_t  *status_out;    // may be null
     uint64_t *elected_bits;  // may be null
-    // narrow summary for the sharded exchange (all may be null):
-    // commit_lo16[g] = commit'[g] - summary_base[g] if that is in [0, 65535), else 65535
+    // narrow summary for the sharded exchange (all may be null): per group
+    // commit'[g] - summary_base[g] in summary_bits (16, 8 or 4) bits, all ones = "does
+    // not fit".  16: uint16 per group; 8: uint8 per group; 4: 16 groups per 64-bit
+    // word (the buffer then must be 8-byte aligned and hold ceil(G/16) words).
     uint16_t *commit_lo16;
-    const T *summary_base;         // null = 0
+    const T *summary_base;         // null = 0; may be the input commit plane (offset = the round's advance)
     uint32_t *summary_escapes;     // incremented once per group that did not fit
+    uint32_t summary_bits;
 };
 typedef rq_round_args_t<int32_t> rq_round_args;
 typedef rq_round_args_t<int64_t> rq_round64_args;

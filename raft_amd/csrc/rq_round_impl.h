@@ -241,25 +241,56 @@ __device__ __forceinline__ T gather_term(const T *p) {
     else return *p;
 }
 
-// 16-bit window of the commit summary: offset from a per-group base, 65535 =
-// "does not fit, fetch the full vector" (counted in summary_escapes).
+// Narrow commit summary: commit' as an offset from a per-group base in `bits`
+// (16, 8 or 4) bits, the all-ones value meaning "does not fit, fetch the full
+// vector" (counted in summary_escapes).  When the base is the round's own input
+// commit plane the offset is the round's advance and the value already in
+// registers is used.  16- and 8-bit values are stored here; 4-bit values are
+// returned (4 bits per group from bit 0) and packed by pack_nibbles() where the
+// whole wave is convergent.
 template <int V, bool NTS, bool FULL, typename T>
-__device__ __forceinline__ void store_commit_lo16(const rq_round_args_t<T> &a, uint32_t g0, int valid,
-                                                  const T (&co)[V]) {
+__device__ __forceinline__ uint32_t store_commit_summary(const rq_round_args_t<T> &a, uint32_t g0, int valid,
+                                                         const T (&co)[V], const T (&cm)[V]) {
+    const uint32_t bits = a.summary_bits;
+    const uint32_t escape = (1u << bits) - 1u;
+    const bool base_is_input = a.summary_base == a.commit;
     uint32_t lo[V];
-    uint32_t escapes = 0;
+    uint32_t escapes = 0, nibbles = 0;
 #pragma unroll
     for (int k = 0; k < V; k++) {
-        const T base = (a.summary_base && k < valid) ? a.summary_base[g0 + k] : 0;
+        T base = 0;
+        if (base_is_input) base = cm[k];
+        else if (a.summary_base && k < valid) base = a.summary_base[g0 + k];
         // unsigned difference: exact whenever co >= base, whatever the magnitudes
         const uint64_t d = (uint64_t)(int64_t)co[k] - (uint64_t)(int64_t)base;
-        const bool fit = co[k] >= base && d < 65535u;
-        lo[k] = fit ? (uint32_t)d : 65535u;
+        const bool fit = co[k] >= base && d < escape;
+        lo[k] = fit ? (uint32_t)d : escape;
         escapes += (!fit && k < valid) ? 1u : 0u;
+        nibbles |= (k < valid ? lo[k] : 0u) << (4 * k);
     }
-    st_u16<V, NTS, FULL>(a.commit_lo16 + g0, valid, lo);
+    if (bits == 16) st_u16<V, NTS, FULL>(a.commit_lo16 + g0, valid, lo);
+    else if (bits == 8) st_u8<V, NTS, FULL>(reinterpret_cast<uint8_t *>(a.commit_lo16) + g0, valid, lo);
     if (escapes && a.summary_escapes) atomicAdd(a.summary_escapes, escapes);
+    return nibbles;
 }
+
+// 4-bit summary: 16 groups per 64-bit word (group g in bits 4*(g%16) of word
+// g/16).  `field` holds the thread's V nibbles, zero for groups outside the
+// batch.  Must be reached by every lane of the wave.
+template <int V>
+__device__ __forceinline__ void pack_nibbles(uint32_t field, uint64_t g0, uint32_t G, uint64_t *words) {
+    constexpr int lanes_per_word = 16 / V;
+    unsigned long long w = (unsigned long long)field << (4 * (g0 & 15));
+#pragma unroll
+    for (int o = lanes_per_word / 2; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
+    if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) words[g0 >> 4] = w;
+}
+
+// What a round body hands back to the kernel for the wave-level packing.
+struct round_fields {
+    uint32_t elected;   // bit k: group g0+k elected
+    uint32_t nibbles;   // 4 bits per group: 4-bit commit summary
+};
 
 // Slot of log[N] inside the group's arena slice, as an unsigned number: with a
 // window, arena slot i holds log[base + i]; N below the base wraps to a huge
@@ -274,7 +305,7 @@ __device__ __forceinline__ typename std::make_unsigned<T>::type window_slot(T nq
 // fixed cluster size n = N for every group
 // ---------------------------------------------------------------------------
 template <int N, int V, int WHAT, int FLAGS, bool FULL, typename T>
-__device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args_t<T> &a,
+__device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T> &a,
                                                      uint32_t g0, int valid,
                                                      const T *lds_log, uint32_t lds_seg0) {
     typedef typename std::make_unsigned<T>::type U;
@@ -346,7 +377,7 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args_t<T> &a
     }
 
     // ---- vote: per-slot predicate, tally ----
-    uint32_t el_field = 0;
+    uint32_t el_field = 0, nib_field = 0;
     if constexpr (DO_VOTE) {
         uint32_t gm[V], sm[V], el[V];
         T mx[V];
@@ -386,10 +417,10 @@ __device__ __forceinline__ uint32_t round_fixed_body(const rq_round_args_t<T> &a
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
         }
         st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
-        if (a.commit_lo16) store_commit_lo16<V, NTS, FULL>(a, g0, valid, co);
+        if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm);
     }
     if (a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return el_field;
+    return round_fields{el_field, nib_field};
 }
 
 template <int N, int V, int WHAT, int FLAGS, typename T>
@@ -416,13 +447,17 @@ __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
         }
         __syncthreads();
     }
-    uint32_t el_field = 0;
+    round_fields f{0, 0};
     if (g0 + V <= a.G)
-        el_field = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, lds_log, lds_seg0);
+        f = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, lds_log, lds_seg0);
     else if (g0 < a.G)
-        el_field = round_fixed_body<N, V, WHAT, FLAGS, false>(a, (uint32_t)g0, (int)(a.G - g0), lds_log, lds_seg0);
+        f = round_fixed_body<N, V, WHAT, FLAGS, false>(a, (uint32_t)g0, (int)(a.G - g0), lds_log, lds_seg0);
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
-        if (a.elected_bits) pack_elected<V>(el_field, g0, a.G, a.elected_bits);
+        if (a.elected_bits) pack_elected<V>(f.elected, g0, a.G, a.elected_bits);
+    }
+    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
+        if (a.commit_lo16 && a.summary_bits == 4)
+            pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));
     }
 }
 
@@ -473,7 +508,7 @@ __device__ __forceinline__ T masked_quorum(const T (&mt)[MMAX][V], int k, uint32
 // mixed cluster sizes).  Null masks mean "all m slots, one configuration".
 // ---------------------------------------------------------------------------
 template <int MMAX, int V, int WHAT, int FLAGS, bool FULL, typename T>
-__device__ __forceinline__ uint32_t round_joint_body(const rq_round_args_t<T> &a,
+__device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T> &a,
                                                      uint32_t g0, int valid,
                                                      bool in_range) {
     typedef typename std::make_unsigned<T>::type U;
@@ -520,7 +555,7 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args_t<T> &a
     // loads are all issued before any of them is consumed, and chunk 0 is issued
     // before the commit side's sort so that it is in flight behind it.
     constexpr int kChunk = 8;
-    uint32_t el_field = 0;
+    uint32_t el_field = 0, nib_field = 0;
     T ct[V], ci[V], mx[V];
     uint32_t gm[V], sm[V];
     T cvt[kChunk][V], cvf[kChunk][V], cll[kChunk][V];
@@ -669,27 +704,31 @@ __device__ __forceinline__ uint32_t round_joint_body(const rq_round_args_t<T> &a
         }
         if (in_range) {
             st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
-            if (a.commit_lo16) store_commit_lo16<V, NTS, FULL>(a, g0, valid, co);
+            if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm);
         }
     }
     if (in_range && a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return el_field;
+    return round_fields{el_field, nib_field};
 }
 
 template <int MMAX, int V, int WHAT, int FLAGS, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-    uint32_t el_field;
+    round_fields f;
     // Every lane runs a body: the wave-wide ballots inside need all of them.
     if (g0 + V <= a.G)
-        el_field = round_joint_body<MMAX, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, true);
+        f = round_joint_body<MMAX, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, true);
     else {
         const bool in_range = g0 < a.G;
-        el_field = round_joint_body<MMAX, V, WHAT, FLAGS, false>(
+        f = round_joint_body<MMAX, V, WHAT, FLAGS, false>(
             a, in_range ? (uint32_t)g0 : 0u, in_range ? (int)(a.G - g0) : 0, in_range);
     }
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
-        if (a.elected_bits) pack_elected<V>(el_field, g0, a.G, a.elected_bits);
+        if (a.elected_bits) pack_elected<V>(f.elected, g0, a.G, a.elected_bits);
+    }
+    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
+        if (a.commit_lo16 && a.summary_bits == 4)
+            pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));
     }
 }
 
@@ -807,7 +846,7 @@ int pick_v(const rq_round_args_t<T> &a, int want, int what) {
     for (int v = want; v > 1; v >>= 1) {
         bool ok = (a.ld % v) == 0;
         if (what & RQ_WHAT_COMMIT)
-            ok = ok && aligned_to(a.commit_lo16, 2 * v) && aligned_to(a.match, E * v) && aligned_to(a.commit, E * v) &&
+            ok = ok && aligned_to(a.commit_lo16, a.summary_bits == 8 ? v : 2 * v) && aligned_to(a.match, E * v) && aligned_to(a.commit, E * v) &&
                  aligned_to(a.leader_term, E * v) && aligned_to(a.log_off, 4 * v) && aligned_to(a.log_base, E * v) &&
                  aligned_to(a.commit_out, E * v);
         if (what & RQ_WHAT_VOTE)
@@ -829,6 +868,9 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if (args.G == 0) return hipSuccess;
     if (args.G > 0x7FFFFFFFu || args.ld < args.G) return hipErrorInvalidValue;
     if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
+    if (args.commit_lo16 && args.summary_bits != 16 && args.summary_bits != 8 && args.summary_bits != 4)
+        return hipErrorInvalidValue;
+    if (args.commit_lo16 && args.summary_bits == 4 && !aligned_to(args.commit_lo16, 8)) return hipErrorInvalidValue;
     if (variant == 0) variant = joint || n > 9 ? RQ_VAR_DEFAULT_JOINT : RQ_VAR_DEFAULT_FIXED;
     const rq_round_args_t<T> &a = args;
     const int flags = variant & (RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE | RQ_VAR_NT_GATHER | RQ_VAR_LDS_LOG);

@@ -20,6 +20,28 @@ def _dev(a, device):
     return torch.from_numpy(np.ascontiguousarray(a)).to(device)
 
 
+def summary_buffer_bytes(groups, bits):
+    """Bytes of the narrow commit summary of `groups` groups: 16/8 bits per group, or
+    4 bits per group packed sixteen to a 64-bit word."""
+    if bits == 4:
+        return 8 * ((groups + 15) // 16)
+    return groups * bits // 8
+
+
+def decode_summary(raw, groups, bits):
+    """Summary buffer (numpy, any dtype) -> uint16 [groups] of offsets; the escape
+    value is (1 << bits) - 1."""
+    b = np.ascontiguousarray(raw).view(np.uint8)[: summary_buffer_bytes(groups, bits)]
+    if bits == 16:
+        return b.view(np.uint16)[:groups].copy()
+    if bits == 8:
+        return b[:groups].astype(np.uint16)
+    nib = np.empty(b.size * 2, np.uint16)
+    nib[0::2] = b & 0x0F            # little-endian words: group g sits in bits 4*(g%16)
+    nib[1::2] = b >> 4
+    return nib[:groups]
+
+
 class DeviceBatch:
     """One batch of groups uploaded to a GPU plus its output buffers."""
 
@@ -27,11 +49,17 @@ class DeviceBatch:
                "voter_term", "voted_for", "last_log_term", "cand_term", "cand_id")
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
-                 share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None):
+                 share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None,
+                 summary_bits=16):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         share_log_with: another DeviceBatch whose log_off/log_term device arrays
-        are reused (the batch must have been generated with the same logs)."""
+        are reused (the batch must have been generated with the same logs).
+        commit_lo16: device buffer for the narrow commit summary in summary_bits
+        (16, 8 or 4) bits per group -- the engine must be set to the same width
+        (DeviceEngine.set_summary_width).  summary_base: a device tensor, None
+        (= 0) or the string "commit" for the batch's own input commit plane (the
+        summary is then the round's advance)."""
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
         G, n, ld = self.G, self.n, self.ld
@@ -76,11 +104,13 @@ class DeviceBatch:
             o["elected_bits"] = elected_bits
         # narrow (16-bit window) commit summary: only written when a buffer is supplied
         if commit_lo16 is not None:
-            assert commit_lo16.numel() == G and commit_lo16.dtype == torch.int16
+            assert commit_lo16.numel() * commit_lo16.element_size() >= summary_buffer_bytes(G, summary_bits)
+            assert commit_lo16.data_ptr() % 8 == 0 or summary_bits != 4
             assert summary_escapes is not None and summary_escapes.dtype == torch.int32
         o["commit_lo16"] = commit_lo16
         o["summary_escapes"] = summary_escapes
-        self.summary_base = summary_base
+        self.summary_bits = summary_bits
+        self.summary_base = self.t["commit"] if isinstance(summary_base, str) else summary_base
         self.o = o
         self._args = {}
         self._plans = []
@@ -106,7 +136,8 @@ class DeviceBatch:
             max_term=o["max_term"].cpu().numpy(),
             status=o["status"].cpu().numpy(),
             elected_bits=o["elected_bits"].cpu().numpy().view(np.uint64),
-            commit_lo16=None if o["commit_lo16"] is None else o["commit_lo16"].cpu().numpy().view(np.uint16),
+            commit_lo16=None if o["commit_lo16"] is None else decode_summary(
+                o["commit_lo16"].cpu().numpy(), self.G, self.summary_bits),
             summary_escapes=None if o["summary_escapes"] is None else int(o["summary_escapes"].cpu()[0]),
         )
 
@@ -131,6 +162,16 @@ class DeviceEngine:
     def _check(self, rc, where):
         if rc != 0:
             raise RqError(rc, where, self._l.rq_last_hip_error(self._h))
+
+    def set_summary_width(self, bits):
+        """Width of the narrow commit summary written by later launches and plans."""
+        self._check(self._l.rq_engine_set_summary_width(self._h, bits), "rq_engine_set_summary_width")
+        self._width = bits
+
+    def _match_width(self, b):
+        """The engine-wide width must be the batch's when its launch or plan is made."""
+        if b.o["commit_lo16"] is not None and getattr(self, "_width", 16) != b.summary_bits:
+            self.set_summary_width(b.summary_bits)
 
     @staticmethod
     def _stream():
@@ -161,10 +202,11 @@ class DeviceEngine:
         every later call is a two-argument rq_plan_launch."""
         if b.wide:
             return self.round64(b, 3, variant, want_bits, status)
-        key = (variant, want_bits, status)
+        key = (variant, want_bits, status, b.summary_bits)
         plan = b._args.get(key)
         if plan is None:
             import ctypes as C
+            self._match_width(b)
             t, o = b.t, b.o
             p = lambda x: None if x is None else x.data_ptr()
             plan = C.c_void_p()
@@ -189,6 +231,7 @@ class DeviceEngine:
     def fused_round_direct(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
         """The same round through rq_fused_round_dev / rq_fused_round_joint_dev (all
         arguments marshalled on every call)."""
+        self._match_width(b)
         t, o = b.t, b.o
         p = lambda x: None if x is None else x.data_ptr()
         tail = [p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
@@ -209,6 +252,7 @@ class DeviceEngine:
         """Enqueue the commit (what & 1) and/or vote (what & 2) decision for a wide
         (int64) DeviceBatch through rq_round64_dev."""
         assert b.wide
+        self._match_width(b)
         t, o = b.t, b.o
         p = lambda x: None if x is None else x.data_ptr()
         rc = self._l.rq_round64_dev(

@@ -11,15 +11,19 @@ heartbeats for all groups.
 Summary per group: the elected decision (1 bit) and the new commitIndex.  xGMI
 is point-to-point (one ~77 GB/s link per peer and direction), and a round of
 1M groups takes ~30 us, so the exchange is sized for the link: by default the
-commitIndex travels as a 16-bit offset from a per-group base (2.1 bytes per
-group with the bit); an offset outside the window is sent as the escape value
-65535, which tells every receiver to fetch the full 32-bit vector of that
-round.  mode="i32" sends the 32-bit vector every round.
+commitIndex travels as an offset from a per-group base in 16, 8 or 4 bits
+(modes "u16", "u8", "u4": 2.1, 1.1 or 0.6 bytes per group with the bit); an
+offset outside the window is sent as the all-ones escape value, which tells
+every receiver to fetch the full 32-bit vector of that round.  With the
+round's own input commitIndex as the base the offset is the round's advance,
+which is what the narrow modes are meant for.  mode="i32" sends the 32-bit
+vector every round.
 """
 import torch
 import torch.distributed as dist
 
 ESCAPE = 65535
+MODE_BITS = {"u16": 16, "u8": 8, "u4": 4, "i32": 32}
 
 
 def shard_bounds(total_groups, world_size, rank):
@@ -33,10 +37,16 @@ def _up8(x):
     return (x + 7) // 8 * 8
 
 
+def commit_section_bytes(groups, mode):
+    bits = MODE_BITS[mode]
+    if bits == 4:
+        return 8 * ((groups + 15) // 16)       # sixteen groups per 64-bit word
+    return groups * bits // 8
+
+
 def summary_bytes(groups, mode="u16"):
     """Bytes of one rank's summary message: commit section (padded to 8), elected bit words."""
-    commit = groups * (2 if mode == "u16" else 4)
-    return _up8(commit) + 8 * ((groups + 63) // 64)
+    return _up8(commit_section_bytes(groups, mode)) + 8 * ((groups + 63) // 64)
 
 
 class SummaryExchange:
@@ -52,7 +62,8 @@ class SummaryExchange:
         call per exchange, a few microseconds of host time), "torch" =
         torch.distributed collectives, "auto" = native on a GPU when every rank
         can create the communicator, else torch."""
-        assert mode in ("u16", "i32") and impl in ("auto", "native", "torch")
+        assert mode in MODE_BITS and impl in ("auto", "native", "torch")
+        self.bits = MODE_BITS[mode]
         self.groups, self.mode = int(groups), mode
         self.device = torch.device(device)
         self.group = group
@@ -61,7 +72,7 @@ class SummaryExchange:
         self.rounds = int(rounds)
         self.round_bytes = summary_bytes(self.groups, mode)
         self.nbytes = self.rounds * self.round_bytes      # one rank's message
-        self._commit_bytes = self.groups * (2 if mode == "u16" else 4)
+        self._commit_bytes = commit_section_bytes(self.groups, mode)
         self._bits_off = _up8(self._commit_bytes)
         self.local = [torch.zeros(self.nbytes, dtype=torch.uint8, device=self.device) for _ in range(depth)]
         self.all = [torch.zeros((self.world, self.nbytes), dtype=torch.uint8, device=self.device)
@@ -82,7 +93,7 @@ class SummaryExchange:
             self._side = torch.cuda.Stream(device=self.device)
             self._done = [torch.cuda.Event() for _ in range(depth)]
             self._pending = [False] * depth
-        dt = torch.int16 if mode == "u16" else torch.int32
+        dt = {32: torch.int32, 16: torch.int16, 8: torch.uint8, 4: torch.int64}[self.bits]
         rb = self.round_bytes
         self._commit_views = [[t[r * rb: r * rb + self._commit_bytes].view(dt) for r in range(self.rounds)]
                               for t in self.local]
@@ -128,8 +139,9 @@ class SummaryExchange:
 
     # ---- views handed to the kernel as outputs --------------------------------
     def commit_view(self, slot, sub=0):
-        """Round `sub` of the slot: int32 [groups] (mode i32) or int16 [groups]
-        holding uint16 offsets (mode u16)."""
+        """Round `sub` of the slot: int32 [groups] (mode i32), int16 [groups] holding
+        uint16 offsets (u16), uint8 [groups] (u8) or int64 [ceil(groups/16)] words of
+        sixteen 4-bit offsets (u4)."""
         return self._commit_views[slot][sub]
 
     def bits_view(self, slot, sub=0):
@@ -198,18 +210,28 @@ class SummaryExchange:
         """elected bits of every rank: int64 [world, ceil(groups/64)]."""
         return self._section(slot, sub, self._bits_off, self.round_bytes).view(torch.int64)
 
+    def _offsets(self, slot, sub):
+        """Narrow modes: the gathered offsets as int32 [world, groups]."""
+        raw = self._section(slot, sub, 0, self._commit_bytes)
+        if self.bits == 16:
+            return (raw.view(torch.int16).to(torch.int32) & 0xFFFF).reshape(self.world, self.groups)
+        if self.bits == 8:
+            return raw.to(torch.int32).reshape(self.world, self.groups)
+        b = raw.reshape(self.world, -1).to(torch.int32)          # little-endian words
+        nib = torch.stack((b & 0x0F, b >> 4), dim=2).reshape(self.world, -1)
+        return nib[:, : self.groups]
+
     def gathered_escapes(self, slot, sub=0):
-        """Groups per rank whose offset left the 16-bit window: int64 [world]
+        """Groups per rank whose offset left the summary window: int64 [world]
         (a reduction over the gathered message; synchronises if on a GPU)."""
         if self.mode == "i32":
             return torch.zeros(self.world, dtype=torch.int64)
-        lo = self._section(slot, sub, 0, self._commit_bytes).view(torch.int16)
-        return (lo.reshape(self.world, self.groups) == -1).sum(dim=1).cpu()      # 0xFFFF
+        return (self._offsets(slot, sub) == (1 << self.bits) - 1).sum(dim=1).cpu()
 
     def gathered_commit(self, slot, sub=0, base=None, full_local_commit=None):
         """commitIndex of every group of every rank: int32 [world, groups].
 
-        mode u16: offsets are added to `base` ([world, groups] int32 or None = 0).
+        Narrow modes: offsets are added to `base` ([world, groups] int32 or None = 0).
         If any rank sent the escape value, `full_local_commit` (this rank's int32
         commit' vector of that round) is all-gathered and used instead; every
         rank sees the same message, so every rank takes this path together."""
@@ -217,7 +239,7 @@ class SummaryExchange:
             return self._section(slot, sub, 0, self._commit_bytes).view(torch.int32).reshape(self.world, self.groups)
         if int(self.gathered_escapes(slot, sub).sum()) > 0:
             if full_local_commit is None:
-                raise RuntimeError("a rank's commit offsets left the 16-bit window: pass full_local_commit")
+                raise RuntimeError("a rank's commit offsets left the summary window: pass full_local_commit")
             if self._full is None:
                 self._full = torch.zeros((self.world, self.groups), dtype=torch.int32, device=self.device)
             if dist.is_initialized():
@@ -225,6 +247,5 @@ class SummaryExchange:
             else:
                 self._full[0].copy_(full_local_commit)
             return self._full
-        lo = self._section(slot, sub, 0, self._commit_bytes).view(torch.int16).reshape(self.world, self.groups)
-        out = lo.to(torch.int32) & 0xFFFF
+        out = self._offsets(slot, sub)
         return out if base is None else out + base

@@ -434,6 +434,48 @@ def test_narrow_commit_summary(dev, variant):
         assert res["summary_escapes"] == int((~fit).sum()) and res["summary_escapes"] > 0
 
 
+@pytest.mark.parametrize("bits", [8, 4])
+@pytest.mark.parametrize("variant", [0, 0x234, 0x132, 0x131])
+def test_commit_summary_widths(dev, variant, bits):
+    """The 8- and 4-bit commit summaries (rq_engine_set_summary_width): offsets from an
+    explicit base and from the round's own input commit plane (the round's advance),
+    fixed, joint and wide kernels, group counts that do not fill the last word."""
+    import torch
+    from raft_amd.device import DeviceBatch, summary_buffer_bytes
+    rng = np.random.default_rng(bits)
+    esc_val = (1 << bits) - 1
+    for kind, G in (("fixed", 70001), ("fixed", 70016), ("joint", 30011), ("wide", 20005), ("fixed", 7)):
+        if kind == "joint":
+            b = synth.gen_mixed(G, seed=3)
+            kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
+        else:
+            b = synth.gen_fused(G, 5, seed=3, ld=G + (G % 4 and 3))
+            kw = {}
+        exp32 = o.fused_round(*b.fused_args(), G=G, **kw)
+        far = rng.random(G) < 0.01
+        for base_kind in ("commit", "explicit"):
+            batch = synth.widen(b)[0] if kind == "wide" else b
+            if base_kind == "explicit":
+                base = np.maximum(exp32["commit"].astype(np.int64) - rng.integers(0, 12, G), 0)
+                base[far] += 40                       # base above commit' -> negative offset -> escape
+                tb = torch.from_numpy(base.astype(batch["commit"].dtype)).to("cuda:0")
+            else:
+                base, tb = b["commit"][:G].astype(np.int64), "commit"
+            buf = torch.full((summary_buffer_bytes(G, bits) + 8,), 0xAB, dtype=torch.uint8, device="cuda:0")
+            esc = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+            db = DeviceBatch(batch, commit_lo16=buf, summary_escapes=esc, summary_base=tb, summary_bits=bits)
+            dev.fused_round(db, variant=variant)
+            res = db.results()
+            assert np.array_equal(res["commit"], exp32["commit"]), (kind, G, base_kind)
+            d = exp32["commit"].astype(np.int64) - base
+            fit = (d >= 0) & (d < esc_val)
+            assert np.array_equal(res["commit_lo16"], np.where(fit, d, esc_val).astype(np.uint16)), (kind, G, base_kind)
+            assert res["summary_escapes"] == int((~fit).sum()), (kind, G, base_kind)
+            # nothing is written past the summary's last word
+            assert bool((buf[summary_buffer_bytes(G, bits):] == 0xAB).all())
+    dev.set_summary_width(16)
+
+
 def test_native_rccl_summary_allgather_one_rank(dev):
     """rq_comm_* (librq's own RCCL communicator, worker thread, side stream) with a
     one-rank communicator: the gathered buffer equals the sent one, slot fencing
