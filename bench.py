@@ -51,7 +51,7 @@ def parse():
     ap.add_argument("--ld-pad", type=int, default=256,
                     help="plane stride = groups + pad (elements): keeps the slot planes off one power-of-two stride")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
-    ap.add_argument("--summary", choices=["u4", "u8", "u16", "i32"], default="u4",
+    ap.add_argument("--summary", choices=["u4", "u8", "u16", "i32"], default="u8",
                     help="commit summary on the wire: u4/u8 = the round's commitIndex advance in 4/8 bits "
                          "(offset from the input commitIndex, all ones = escape), u16 = 16-bit offset from 0, "
                          "i32 = the full vector")
@@ -100,6 +100,11 @@ def cpu_baseline(args, synth):
 
 def main():
     args = parse()
+    # Libraries (RCCL's version banner, for one) write to stdout; the contract is ONE
+    # JSON line there, so everything else is sent to stderr until the line is printed.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if os.environ.get("RQ_BENCH_TRACE_AFTER"):       # debugging aid: dump Python stacks if stuck
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["RQ_BENCH_TRACE_AFTER"]), exit=True)
@@ -259,6 +264,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "fused":
             line["cpu_baseline"] = cpu_baseline(args, synth)
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
         print(json.dumps(line), flush=True)
 
     eng.close()
