@@ -8,7 +8,7 @@ CSRC     = raft_amd/csrc
 
 all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h include/rq.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h $(CSRC)/rq_append_impl.h include/rq.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

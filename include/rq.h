@@ -379,6 +379,30 @@ int rq_round64_dev(rq_engine *e, void *stream, int variant, int what,
                    uint16_t *commit_lo16, const int64_t *summary_base,
                    uint32_t *summary_escapes);
 
+/* Wide forms of rq_follower_clamp, rq_append_check and rq_append_check_dev
+ * (same rules; int64 planes, 32-bit log offsets). */
+int rq_follower_clamp64(rq_engine *e, uint64_t count, const int64_t *leader_commit,
+                        const int64_t *commit, const int64_t *last_new_index,
+                        int64_t *commit_out);
+int rq_append_check64(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                      const uint16_t *active_mask,
+                      const int64_t *follower_term, const int64_t *leader_term,
+                      const int64_t *prev_log_index, const int64_t *prev_log_term,
+                      const int64_t *n_new,
+                      const uint32_t *flog_off, const int64_t *flog_term,
+                      int64_t *follower_term_out, uint16_t *success_mask,
+                      uint16_t *stepdown_mask, int64_t *match_index_io,
+                      int64_t *next_index_io, uint8_t *status_out);
+int rq_append_check64_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
+                          const uint16_t *active_mask,
+                          const int64_t *follower_term, const int64_t *leader_term,
+                          const int64_t *prev_log_index, const int64_t *prev_log_term,
+                          const int64_t *n_new,
+                          const uint32_t *flog_off, const int64_t *flog_term,
+                          int64_t *follower_term_out, uint16_t *success_mask,
+                          uint16_t *stepdown_mask, int64_t *match_index_io,
+                          int64_t *next_index_io, uint8_t *status_out);
+
 /* Device memory for hosts that keep group state resident without another GPU
  * runtime binding (a Go host has none), to be used with the *_dev launches.
  * kind selects the hipExtMallocWithFlags flavour: 0 = ordinary device memory,

@@ -517,64 +517,81 @@ int orc_follower_clamp(uint64_t count, const int32_t *leader_commit,
     return 0;
 }
 
+int orc_follower_clamp64(uint64_t count, const int64_t *leader_commit,
+                         const int64_t *commit, const int64_t *last_new_index,
+                         int64_t *commit_out) {
+    for (uint64_t i = 0; i < count; i++) {
+        int64_t ci = commit[i];
+        if (leader_commit[i] > ci) ci = rf_min_int(leader_commit[i], last_new_index[i]);
+        commit_out[i] = ci;
+    }
+    return 0;
+}
+
 /* raft.go:142-153 for every (group, follower) slot s = p*ld + g: abdication,
  * the term gate and the prevLogIndex/prevLogTerm consistency check (direct
  * slot indexing, :151), then the leader's bookkeeping for the reply.  Follower
  * logs are a CSR arena indexed by slot.  Slots outside active_mask (NULL = all
  * n) receive no RPC and are left untouched. */
-int orc_append_check(uint32_t G, uint32_t n, uint32_t ld,
-                     const uint16_t *active_mask,
-                     const int32_t *follower_term, const int32_t *leader_term,
-                     const int32_t *prev_log_index, const int32_t *prev_log_term,
-                     const int32_t *n_new,
-                     const uint32_t *flog_off, const int32_t *flog_term,
-                     int32_t *follower_term_out, uint16_t *success_mask,
-                     uint16_t *stepdown_mask, int32_t *match_index_io,
-                     int32_t *next_index_io, uint8_t *status_out) {
-    if (n < 1 || n > ORC_MAX_SLOTS || ld < G) return -1;
-    for (uint32_t g = 0; g < G; g++) {
-        uint32_t ok = 0, sd = 0; uint8_t st = 0;
-        uint32_t act = active_mask ? active_mask[g] : 0xFFFFu;
-        rf_node L; memset(&L, 0, sizeof L);
-        int64_t mi[ORC_MAX_SLOTS], ni[ORC_MAX_SLOTS];
-        L.n_peers = n; L.match_index = mi; L.next_index = ni;
-        for (uint32_t p = 0; p < n; p++) {
-            size_t s = (size_t)p * ld + g;
-            mi[p] = match_index_io ? match_index_io[s] : 0;
-            ni[p] = next_index_io ? next_index_io[s] : 1;
-        }
-        for (uint32_t p = 0; p < n; p++) {
-            if (!(act >> p & 1)) continue;
-            size_t s = (size_t)p * ld + g;
-            int64_t len = (int64_t)flog_off[s + 1] - (int64_t)flog_off[s];
-            rf_entry stack_log[64];
-            rf_entry *log = len <= 64 ? stack_log : (rf_entry *)malloc((size_t)len * sizeof(rf_entry));
-            for (int64_t i = 0; i < len; i++) { log[i].command = ""; log[i].index = i; log[i].term_num = flog_term[flog_off[s] + i]; }
-            rf_node f; memset(&f, 0, sizeof f);
-            f.node_type = RF_CANDIDATE; f.current_term = follower_term[s];
-            f.voted_for = -1; f.log = log; f.log_len = len; f.log_cap = len;
-            int64_t before = f.current_term, tr; int success;
-            /* no new entries and leaderCommit 0 keep :158-176 inert */
-            int rc = rf_append_entries_rpc(&f, leader_term[g], 0, prev_log_index[s],
-                                           prev_log_term[s], NULL, 0, 0, &tr, &success);
-            if (rc != RF_OK) st |= ORC_ST_LOG_OOB;
-            if (leader_term[g] > before) sd |= 1u << p;
-            if (success) ok |= 1u << p;
-            follower_term_out[s] = (int32_t)f.current_term;
-            rf_leader_on_append_reply(&L, p, success, leader_term[g] >= before,
-                                      prev_log_index[s], n_new ? n_new[s] : 0);
-            if (f.log != stack_log) free(f.log);
-        }
-        for (uint32_t p = 0; p < n; p++) {
-            size_t s = (size_t)p * ld + g;
-            if (match_index_io) match_index_io[s] = (int32_t)mi[p];
-            if (next_index_io) next_index_io[s] = (int32_t)ni[p];
-        }
-        success_mask[g] = (uint16_t)ok; stepdown_mask[g] = (uint16_t)sd;
-        if (status_out) status_out[g] = st;
-    }
-    return 0;
+/* One body, two element widths: T = int32_t (orc_append_check) and int64_t
+ * (orc_append_check64). */
+#define ORC_DEFINE_APPEND_CHECK(NAME, T) \
+int NAME(uint32_t G, uint32_t n, uint32_t ld, \
+                     const uint16_t *active_mask, \
+                     const T *follower_term, const T *leader_term, \
+                     const T *prev_log_index, const T *prev_log_term, \
+                     const T *n_new, \
+                     const uint32_t *flog_off, const T *flog_term, \
+                     T *follower_term_out, uint16_t *success_mask, \
+                     uint16_t *stepdown_mask, T *match_index_io, \
+                     T *next_index_io, uint8_t *status_out) { \
+    if (n < 1 || n > ORC_MAX_SLOTS || ld < G) return -1; \
+    for (uint32_t g = 0; g < G; g++) { \
+        uint32_t ok = 0, sd = 0; uint8_t st = 0; \
+        uint32_t act = active_mask ? active_mask[g] : 0xFFFFu; \
+        rf_node L; memset(&L, 0, sizeof L); \
+        int64_t mi[ORC_MAX_SLOTS], ni[ORC_MAX_SLOTS]; \
+        L.n_peers = n; L.match_index = mi; L.next_index = ni; \
+        for (uint32_t p = 0; p < n; p++) { \
+            size_t s = (size_t)p * ld + g; \
+            mi[p] = match_index_io ? match_index_io[s] : 0; \
+            ni[p] = next_index_io ? next_index_io[s] : 1; \
+        } \
+        for (uint32_t p = 0; p < n; p++) { \
+            if (!(act >> p & 1)) continue; \
+            size_t s = (size_t)p * ld + g; \
+            int64_t len = (int64_t)flog_off[s + 1] - (int64_t)flog_off[s]; \
+            rf_entry stack_log[64]; \
+            rf_entry *log = len <= 64 ? stack_log : (rf_entry *)malloc((size_t)len * sizeof(rf_entry)); \
+            for (int64_t i = 0; i < len; i++) { log[i].command = ""; log[i].index = i; log[i].term_num = flog_term[flog_off[s] + i]; } \
+            rf_node f; memset(&f, 0, sizeof f); \
+            f.node_type = RF_CANDIDATE; f.current_term = follower_term[s]; \
+            f.voted_for = -1; f.log = log; f.log_len = len; f.log_cap = len; \
+            int64_t before = f.current_term, tr; int success; \
+            /* no new entries and leaderCommit 0 keep :158-176 inert */ \
+            int rc = rf_append_entries_rpc(&f, leader_term[g], 0, prev_log_index[s], \
+                                           prev_log_term[s], NULL, 0, 0, &tr, &success); \
+            if (rc != RF_OK) st |= ORC_ST_LOG_OOB; \
+            if (leader_term[g] > before) sd |= 1u << p; \
+            if (success) ok |= 1u << p; \
+            follower_term_out[s] = (T)f.current_term; \
+            rf_leader_on_append_reply(&L, p, success, leader_term[g] >= before, \
+                                      prev_log_index[s], n_new ? n_new[s] : 0); \
+            if (f.log != stack_log) free(f.log); \
+        } \
+        for (uint32_t p = 0; p < n; p++) { \
+            size_t s = (size_t)p * ld + g; \
+            if (match_index_io) match_index_io[s] = (T)mi[p]; \
+            if (next_index_io) next_index_io[s] = (T)ni[p]; \
+        } \
+        success_mask[g] = (uint16_t)ok; stepdown_mask[g] = (uint16_t)sd; \
+        if (status_out) status_out[g] = st; \
+    } \
+    return 0; \
 }
+
+ORC_DEFINE_APPEND_CHECK(orc_append_check, int32_t)
+ORC_DEFINE_APPEND_CHECK(orc_append_check64, int64_t)
 
 /* ------------------------------------------------------------------------ */
 /* CPU baseline: heap-allocated reference-shaped clusters                    */

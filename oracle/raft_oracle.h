@@ -148,6 +148,20 @@ int orc_append_check(uint32_t G, uint32_t n, uint32_t ld,
                      uint16_t *stepdown_mask, int32_t *match_index_io,
                      int32_t *next_index_io, uint8_t *status_out); /* :142-153 */
 
+/* wide-layout forms of the two functions above */
+int orc_follower_clamp64(uint64_t count, const int64_t *leader_commit,
+                         const int64_t *commit, const int64_t *last_new_index,
+                         int64_t *commit_out);
+int orc_append_check64(uint32_t G, uint32_t n, uint32_t ld,
+                       const uint16_t *active_mask,
+                       const int64_t *follower_term, const int64_t *leader_term,
+                       const int64_t *prev_log_index, const int64_t *prev_log_term,
+                       const int64_t *n_new,
+                       const uint32_t *flog_off, const int64_t *flog_term,
+                       int64_t *follower_term_out, uint16_t *success_mask,
+                       uint16_t *stepdown_mask, int64_t *match_index_io,
+                       int64_t *next_index_io, uint8_t *status_out);
+
 /* ---- CPU baseline: reference-shaped heap objects, timed ---- */
 typedef struct orc_cluster_set orc_cluster_set;
 orc_cluster_set *orc_bench_build(uint32_t G, uint32_t n, uint32_t ld,

@@ -53,6 +53,9 @@ PROTOTYPES = {
     "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 24,
     # wide layout: what, G, m, ld, then 2 masks + 11 inputs + 7 outputs (host) / + 4 summary (device)
     "rq_round64": [vp, cint, u32, u32, u32] + [vp] * 20,
+    "rq_follower_clamp64": [vp, u64, vp, vp, vp, vp],
+    "rq_append_check64": [vp, u32, u32, u32] + [vp] * 14,
+    "rq_append_check64_dev": [vp, vp, u32, u32, u32] + [vp] * 14,
     "rq_round64_dev": [vp, vp, cint, cint, u32, u32, u32] + [vp] * 24,
     "rq_plan_fused_round": [vp, cint, cint, u32, u32, u32] + [vp] * 24 + [C.POINTER(vp)],
     "rq_plan_launch": [vp, vp],

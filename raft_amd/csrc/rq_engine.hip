@@ -292,6 +292,133 @@ int dev_launch(rq_engine *e, void *stream, int variant, uint32_t n, bool joint, 
     return RQ_OK;
 }
 
+template <typename T>
+int follower_clamp_host(rq_engine *e, uint64_t count, const T *leader_commit, const T *commit,
+                        const T *last_new_index, T *commit_out) {
+    if (!e || !leader_commit || !commit || !last_new_index || !commit_out) return RQ_E_ARG;
+    if (count > (uint64_t)e->max_slots * e->ld) return RQ_E_RANGE;
+    std::lock_guard<std::mutex> lk(e->mu);
+    RQ_HIP(e, hipSetDevice(e->device));
+    e->resident = false;
+    if (count == 0) return RQ_OK;
+    staging<T> s;
+    RQ_TRY(get_staging(e, s));
+    const size_t bytes = (size_t)count * sizeof(T);
+    RQ_TRY(h2d(e, s.match, leader_commit, bytes));
+    RQ_TRY(h2d(e, s.voter_term, commit, bytes));
+    RQ_TRY(h2d(e, s.voted_for, last_new_index, bytes));
+    RQ_HIP(e, rq_launch_follower_clamp(count, s.match, s.voter_term, s.voted_for, s.last_log_term, e->stream));
+    RQ_TRY(d2h(e, commit_out, s.last_log_term, bytes));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+template <typename T>
+int append_args_ok(const rq_append_args_t<T> &a) {
+    if (a.n < 1 || a.n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
+    if (!a.follower_term || !a.leader_term || !a.prev_log_index || !a.prev_log_term ||
+        !a.flog_off || !a.flog_term || !a.follower_term_out || !a.success_mask || !a.stepdown_mask)
+        return RQ_E_ARG;
+    return RQ_OK;
+}
+
+// h holds the caller's HOST pointers; stages everything into the grow-only aux
+// buffer, launches, copies the outputs back.
+template <typename T>
+int append_check_host(rq_engine *e, const rq_append_args_t<T> &h) {
+    if (!e) return RQ_E_ARG;
+    RQ_TRY(append_args_ok(h));
+    const uint32_t G = h.G, n = h.n, ld = h.ld;
+    constexpr size_t E = sizeof(T);
+    if (G > e->max_groups) return RQ_E_RANGE;
+    if (G == 0) return RQ_OK;
+    const size_t slots = (size_t)n * ld;
+    for (size_t i = 0; i < slots; i++)
+        if (h.flog_off[i + 1] < h.flog_off[i]) return RQ_E_ARG;
+    const size_t arena = h.flog_off[slots];
+    // device image: 7 planes, offsets, arena, 2 masks (+1 input mask), status, leader terms
+    const size_t plane = up(slots * E);
+    const size_t total = 7 * plane + up((slots + 1) * 4) + up(arena * E + E) + 3 * up((size_t)G * 2) +
+                         up(G) + up((size_t)G * E);
+    std::lock_guard<std::mutex> lk(e->mu);
+    RQ_HIP(e, hipSetDevice(e->device));
+    if (total > e->aux_bytes) {
+        if (e->aux) { RQ_HIP(e, hipFree(e->aux)); e->aux = nullptr; e->aux_bytes = 0; }
+        if (hipMalloc((void **)&e->aux, total) != hipSuccess) return RQ_E_NOMEM;
+        e->aux_bytes = total;
+    }
+    char *p = e->aux;
+    auto take = [&p](size_t bytes) { char *r = p; p += bytes; return r; };
+    T *d_ft = (T *)take(plane), *d_pi = (T *)take(plane), *d_pt = (T *)take(plane);
+    T *d_nn = (T *)take(plane), *d_mi = (T *)take(plane), *d_ni = (T *)take(plane);
+    T *d_fo = (T *)take(plane);
+    uint32_t *d_off = (uint32_t *)take(up((slots + 1) * 4));
+    T *d_arena = (T *)take(up(arena * E + E));
+    uint16_t *d_act = (uint16_t *)take(up((size_t)G * 2));
+    uint16_t *d_ok = (uint16_t *)take(up((size_t)G * 2)), *d_sd = (uint16_t *)take(up((size_t)G * 2));
+    uint8_t *d_st = (uint8_t *)take(up(G));
+    T *d_lt = (T *)take(up((size_t)G * E));
+    RQ_TRY(h2d(e, d_ft, h.follower_term, slots * E));
+    RQ_TRY(h2d(e, d_pi, h.prev_log_index, slots * E));
+    RQ_TRY(h2d(e, d_pt, h.prev_log_term, slots * E));
+    if (h.n_new) RQ_TRY(h2d(e, d_nn, h.n_new, slots * E));
+    if (h.match_index_io) RQ_TRY(h2d(e, d_mi, h.match_index_io, slots * E));
+    if (h.next_index_io) RQ_TRY(h2d(e, d_ni, h.next_index_io, slots * E));
+    // slots that receive no RPC keep the caller's term in the output plane
+    RQ_TRY(h2d(e, d_fo, h.follower_term, slots * E));
+    RQ_TRY(h2d(e, d_off, h.flog_off, (slots + 1) * 4));
+    RQ_TRY(h2d(e, d_arena, h.flog_term, arena * E));
+    if (h.active_mask) RQ_TRY(h2d(e, d_act, h.active_mask, (size_t)G * 2));
+    RQ_TRY(h2d(e, d_lt, h.leader_term, (size_t)G * E));
+    rq_append_args_t<T> a = h;
+    a.active_mask = h.active_mask ? d_act : nullptr;
+    a.follower_term = d_ft; a.leader_term = d_lt; a.prev_log_index = d_pi; a.prev_log_term = d_pt;
+    a.n_new = h.n_new ? d_nn : nullptr; a.flog_off = d_off; a.flog_term = d_arena;
+    a.follower_term_out = d_fo; a.success_mask = d_ok; a.stepdown_mask = d_sd;
+    a.match_index_io = h.match_index_io ? d_mi : nullptr;
+    a.next_index_io = h.next_index_io ? d_ni : nullptr;
+    a.status_out = d_st;
+    RQ_HIP(e, rq_launch_append_check(a, e->stream));
+    RQ_TRY(d2h(e, h.follower_term_out, d_fo, slots * E));
+    RQ_TRY(d2h(e, h.success_mask, d_ok, (size_t)G * 2));
+    RQ_TRY(d2h(e, h.stepdown_mask, d_sd, (size_t)G * 2));
+    RQ_TRY(d2h(e, h.match_index_io, d_mi, slots * E));
+    RQ_TRY(d2h(e, h.next_index_io, d_ni, slots * E));
+    RQ_TRY(d2h(e, h.status_out, d_st, G));
+    RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return RQ_OK;
+}
+
+template <typename T>
+int append_check_dev(rq_engine *e, void *stream, const rq_append_args_t<T> &a) {
+    if (!e) return RQ_E_ARG;
+    RQ_TRY(append_args_ok(a));
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipError_t err = rq_launch_append_check(a, (hipStream_t)stream);
+    if (err == hipErrorInvalidValue) return RQ_E_ARG;
+    RQ_HIP(e, err);
+    return RQ_OK;
+}
+
+template <typename T>
+rq_append_args_t<T> make_append_args(uint32_t G, uint32_t n, uint32_t ld, const uint16_t *active_mask,
+                                     const T *follower_term, const T *leader_term,
+                                     const T *prev_log_index, const T *prev_log_term, const T *n_new,
+                                     const uint32_t *flog_off, const T *flog_term,
+                                     T *follower_term_out, uint16_t *success_mask,
+                                     uint16_t *stepdown_mask, T *match_index_io, T *next_index_io,
+                                     uint8_t *status_out) {
+    rq_append_args_t<T> h;
+    std::memset(&h, 0, sizeof h);
+    h.G = G; h.ld = ld; h.n = n; h.active_mask = active_mask;
+    h.follower_term = follower_term; h.leader_term = leader_term;
+    h.prev_log_index = prev_log_index; h.prev_log_term = prev_log_term; h.n_new = n_new;
+    h.flog_off = flog_off; h.flog_term = flog_term; h.follower_term_out = follower_term_out;
+    h.success_mask = success_mask; h.stepdown_mask = stepdown_mask;
+    h.match_index_io = match_index_io; h.next_index_io = next_index_io; h.status_out = status_out;
+    return h;
+}
+
 }  // namespace
 
 extern "C" {
@@ -501,29 +628,13 @@ int rq_fused_round_joint(rq_engine *e, uint32_t G, uint32_t m, uint32_t ld,
 int rq_follower_clamp(rq_engine *e, uint64_t count, const int32_t *leader_commit,
                       const int32_t *commit, const int32_t *last_new_index,
                       int32_t *commit_out) {
-    if (!e || !leader_commit || !commit || !last_new_index || !commit_out) return RQ_E_ARG;
-    if (count > (uint64_t)e->max_slots * e->ld) return RQ_E_RANGE;
-    std::lock_guard<std::mutex> lk(e->mu);
-    RQ_HIP(e, hipSetDevice(e->device));
-    e->resident = false;
-    if (count == 0) return RQ_OK;
-    const size_t bytes = (size_t)count * 4;
-    RQ_TRY(h2d(e, e->match, leader_commit, bytes));
-    RQ_TRY(h2d(e, e->voter_term, commit, bytes));
-    RQ_TRY(h2d(e, e->voted_for, last_new_index, bytes));
-    RQ_HIP(e, rq_launch_follower_clamp(count, e->match, e->voter_term, e->voted_for,
-                                       e->last_log_term, e->stream));
-    RQ_TRY(d2h(e, commit_out, e->last_log_term, bytes));
-    RQ_HIP(e, hipStreamSynchronize(e->stream));
-    return RQ_OK;
+    return follower_clamp_host(e, count, leader_commit, commit, last_new_index, commit_out);
 }
 
-static int append_args_ok(const rq_append_args &a) {
-    if (a.n < 1 || a.n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
-    if (!a.follower_term || !a.leader_term || !a.prev_log_index || !a.prev_log_term ||
-        !a.flog_off || !a.flog_term || !a.follower_term_out || !a.success_mask || !a.stepdown_mask)
-        return RQ_E_ARG;
-    return RQ_OK;
+int rq_follower_clamp64(rq_engine *e, uint64_t count, const int64_t *leader_commit,
+                        const int64_t *commit, const int64_t *last_new_index,
+                        int64_t *commit_out) {
+    return follower_clamp_host(e, count, leader_commit, commit, last_new_index, commit_out);
 }
 
 int rq_append_check(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
@@ -533,98 +644,49 @@ int rq_append_check(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
                     const uint32_t *flog_off, const int32_t *flog_term,
                     int32_t *follower_term_out, uint16_t *success_mask, uint16_t *stepdown_mask,
                     int32_t *match_index_io, int32_t *next_index_io, uint8_t *status_out) {
-    if (!e) return RQ_E_ARG;
-    rq_append_args h;
-    std::memset(&h, 0, sizeof h);
-    h.G = G; h.ld = ld; h.n = n; h.active_mask = active_mask;
-    h.follower_term = follower_term; h.leader_term = leader_term;
-    h.prev_log_index = prev_log_index; h.prev_log_term = prev_log_term; h.n_new = n_new;
-    h.flog_off = flog_off; h.flog_term = flog_term; h.follower_term_out = follower_term_out;
-    h.success_mask = success_mask; h.stepdown_mask = stepdown_mask;
-    h.match_index_io = match_index_io; h.next_index_io = next_index_io; h.status_out = status_out;
-    RQ_TRY(append_args_ok(h));
-    if (G > e->max_groups) return RQ_E_RANGE;
-    if (G == 0) return RQ_OK;
-    const size_t slots = (size_t)n * ld;
-    for (size_t i = 0; i < slots; i++)
-        if (flog_off[i + 1] < flog_off[i]) return RQ_E_ARG;
-    const size_t arena = flog_off[slots];
-    // device image: 7 planes, offsets, arena, 2 masks (+1 input mask), status, leader terms
-    const size_t plane = up(slots * 4);
-    const size_t total = 7 * plane + up((slots + 1) * 4) + up(arena * 4 + 4) + 3 * up((size_t)G * 2) +
-                         up(G) + up((size_t)G * 4);
-    std::lock_guard<std::mutex> lk(e->mu);
-    RQ_HIP(e, hipSetDevice(e->device));
-    if (total > e->aux_bytes) {
-        if (e->aux) { RQ_HIP(e, hipFree(e->aux)); e->aux = nullptr; e->aux_bytes = 0; }
-        if (hipMalloc((void **)&e->aux, total) != hipSuccess) return RQ_E_NOMEM;
-        e->aux_bytes = total;
-    }
-    char *p = e->aux;
-    auto take = [&p](size_t bytes) { char *r = p; p += bytes; return r; };
-    int32_t *d_ft = (int32_t *)take(plane), *d_pi = (int32_t *)take(plane), *d_pt = (int32_t *)take(plane);
-    int32_t *d_nn = (int32_t *)take(plane), *d_mi = (int32_t *)take(plane), *d_ni = (int32_t *)take(plane);
-    int32_t *d_fo = (int32_t *)take(plane);
-    uint32_t *d_off = (uint32_t *)take(up((slots + 1) * 4));
-    int32_t *d_arena = (int32_t *)take(up(arena * 4 + 4));
-    uint16_t *d_act = (uint16_t *)take(up((size_t)G * 2));
-    uint16_t *d_ok = (uint16_t *)take(up((size_t)G * 2)), *d_sd = (uint16_t *)take(up((size_t)G * 2));
-    uint8_t *d_st = (uint8_t *)take(up(G));
-    int32_t *d_lt = (int32_t *)take(up((size_t)G * 4));
-    RQ_TRY(h2d(e, d_ft, follower_term, slots * 4));
-    RQ_TRY(h2d(e, d_pi, prev_log_index, slots * 4));
-    RQ_TRY(h2d(e, d_pt, prev_log_term, slots * 4));
-    if (n_new) RQ_TRY(h2d(e, d_nn, n_new, slots * 4));
-    if (match_index_io) RQ_TRY(h2d(e, d_mi, match_index_io, slots * 4));
-    if (next_index_io) RQ_TRY(h2d(e, d_ni, next_index_io, slots * 4));
-    // slots that receive no RPC keep the caller's term in the output plane
-    RQ_TRY(h2d(e, d_fo, follower_term, slots * 4));
-    RQ_TRY(h2d(e, d_off, flog_off, (slots + 1) * 4));
-    RQ_TRY(h2d(e, d_arena, flog_term, arena * 4));
-    if (active_mask) RQ_TRY(h2d(e, d_act, active_mask, (size_t)G * 2));
-    RQ_TRY(h2d(e, d_lt, leader_term, (size_t)G * 4));
-    rq_append_args a = h;
-    a.active_mask = active_mask ? d_act : nullptr;
-    a.follower_term = d_ft; a.leader_term = d_lt; a.prev_log_index = d_pi; a.prev_log_term = d_pt;
-    a.n_new = n_new ? d_nn : nullptr; a.flog_off = d_off; a.flog_term = d_arena;
-    a.follower_term_out = d_fo; a.success_mask = d_ok; a.stepdown_mask = d_sd;
-    a.match_index_io = match_index_io ? d_mi : nullptr;
-    a.next_index_io = next_index_io ? d_ni : nullptr;
-    a.status_out = d_st;
-    RQ_HIP(e, rq_launch_append_check(a, e->stream));
-    RQ_TRY(d2h(e, follower_term_out, d_fo, slots * 4));
-    RQ_TRY(d2h(e, success_mask, d_ok, (size_t)G * 2));
-    RQ_TRY(d2h(e, stepdown_mask, d_sd, (size_t)G * 2));
-    RQ_TRY(d2h(e, match_index_io, d_mi, slots * 4));
-    RQ_TRY(d2h(e, next_index_io, d_ni, slots * 4));
-    RQ_TRY(d2h(e, status_out, d_st, G));
-    RQ_HIP(e, hipStreamSynchronize(e->stream));
-    return RQ_OK;
+    return append_check_host(e, make_append_args(G, n, ld, active_mask, follower_term, leader_term, prev_log_index,
+                                             prev_log_term, n_new, flog_off, flog_term, follower_term_out,
+                                             success_mask, stepdown_mask, match_index_io, next_index_io,
+                                             status_out));
+}
+
+int rq_append_check64(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
+                    const uint16_t *active_mask, const int64_t *follower_term,
+                    const int64_t *leader_term, const int64_t *prev_log_index,
+                    const int64_t *prev_log_term, const int64_t *n_new,
+                    const uint32_t *flog_off, const int64_t *flog_term,
+                    int64_t *follower_term_out, uint16_t *success_mask, uint16_t *stepdown_mask,
+                    int64_t *match_index_io, int64_t *next_index_io, uint8_t *status_out) {
+    return append_check_host(e, make_append_args(G, n, ld, active_mask, follower_term, leader_term, prev_log_index,
+                                             prev_log_term, n_new, flog_off, flog_term, follower_term_out,
+                                             success_mask, stepdown_mask, match_index_io, next_index_io,
+                                             status_out));
 }
 
 int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
-                        const uint16_t *active_mask, const int32_t *follower_term,
-                        const int32_t *leader_term, const int32_t *prev_log_index,
-                        const int32_t *prev_log_term, const int32_t *n_new,
-                        const uint32_t *flog_off, const int32_t *flog_term,
-                        int32_t *follower_term_out, uint16_t *success_mask,
-                        uint16_t *stepdown_mask, int32_t *match_index_io,
-                        int32_t *next_index_io, uint8_t *status_out) {
-    if (!e) return RQ_E_ARG;
-    rq_append_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.n = n; a.active_mask = active_mask;
-    a.follower_term = follower_term; a.leader_term = leader_term;
-    a.prev_log_index = prev_log_index; a.prev_log_term = prev_log_term; a.n_new = n_new;
-    a.flog_off = flog_off; a.flog_term = flog_term; a.follower_term_out = follower_term_out;
-    a.success_mask = success_mask; a.stepdown_mask = stepdown_mask;
-    a.match_index_io = match_index_io; a.next_index_io = next_index_io; a.status_out = status_out;
-    RQ_TRY(append_args_ok(a));
-    RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = rq_launch_append_check(a, (hipStream_t)stream);
-    if (err == hipErrorInvalidValue) return RQ_E_ARG;
-    RQ_HIP(e, err);
-    return RQ_OK;
+                    const uint16_t *active_mask, const int32_t *follower_term,
+                    const int32_t *leader_term, const int32_t *prev_log_index,
+                    const int32_t *prev_log_term, const int32_t *n_new,
+                    const uint32_t *flog_off, const int32_t *flog_term,
+                    int32_t *follower_term_out, uint16_t *success_mask, uint16_t *stepdown_mask,
+                    int32_t *match_index_io, int32_t *next_index_io, uint8_t *status_out) {
+    return append_check_dev(e, stream, make_append_args(G, n, ld, active_mask, follower_term, leader_term, prev_log_index,
+                                             prev_log_term, n_new, flog_off, flog_term, follower_term_out,
+                                             success_mask, stepdown_mask, match_index_io, next_index_io,
+                                             status_out));
+}
+
+int rq_append_check64_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
+                    const uint16_t *active_mask, const int64_t *follower_term,
+                    const int64_t *leader_term, const int64_t *prev_log_index,
+                    const int64_t *prev_log_term, const int64_t *n_new,
+                    const uint32_t *flog_off, const int64_t *flog_term,
+                    int64_t *follower_term_out, uint16_t *success_mask, uint16_t *stepdown_mask,
+                    int64_t *match_index_io, int64_t *next_index_io, uint8_t *status_out) {
+    return append_check_dev(e, stream, make_append_args(G, n, ld, active_mask, follower_term, leader_term, prev_log_index,
+                                             prev_log_term, n_new, flog_off, flog_term, follower_term_out,
+                                             success_mask, stepdown_mask, match_index_io, next_index_io,
+                                             status_out));
 }
 
 int rq_upload(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,

@@ -87,27 +87,35 @@ hipError_t rq_launch_round(const rq_round64_args &a, uint32_t n, bool joint,
 // AppendEntries receiver-side consistency batch (raft.go:142-153) plus the
 // leader's nextIndex/matchIndex bookkeeping for the replies.  Slot id
 // s = p * ld + g indexes both the planes and the follower-log CSR offsets.
-struct rq_append_args {
+template <typename T>
+struct rq_append_args_t {
     uint32_t G, ld, n;
     const uint16_t *active_mask;    // may be null: all n slots receive the RPC
-    const int32_t  *follower_term;  // [n][ld]
-    const int32_t  *leader_term;    // [G]
-    const int32_t  *prev_log_index; // [n][ld]
-    const int32_t  *prev_log_term;  // [n][ld]
-    const int32_t  *n_new;          // [n][ld], may be null (0)
+    const T *follower_term;         // [n][ld]
+    const T *leader_term;           // [G]
+    const T *prev_log_index;        // [n][ld]
+    const T *prev_log_term;         // [n][ld]
+    const T *n_new;                 // [n][ld], may be null (0)
     const uint32_t *flog_off;       // [n*ld + 1]
-    const int32_t  *flog_term;
-    int32_t  *follower_term_out;    // [n][ld]
+    const T *flog_term;
+    T *follower_term_out;           // [n][ld]
     uint16_t *success_mask;         // [G]
     uint16_t *stepdown_mask;        // [G]
-    int32_t  *match_index_io;       // [n][ld], may be null
-    int32_t  *next_index_io;        // [n][ld], may be null
+    T *match_index_io;              // [n][ld], may be null
+    T *next_index_io;               // [n][ld], may be null
     uint8_t  *status_out;           // [G], may be null
 };
+typedef rq_append_args_t<int32_t> rq_append_args;
+typedef rq_append_args_t<int64_t> rq_append64_args;
 hipError_t rq_launch_append_check(const rq_append_args &a, hipStream_t stream);
+hipError_t rq_launch_append_check(const rq_append64_args &a, hipStream_t stream);
 
 // commit'[i] = lc[i] > ci[i] ? min(lc[i], last_new[i]) : ci[i]   (raft.go:172-176)
 hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,
                                     const int32_t *commit,
                                     const int32_t *last_new_index,
                                     int32_t *commit_out, hipStream_t stream);
+hipError_t rq_launch_follower_clamp(uint64_t count, const int64_t *leader_commit,
+                                    const int64_t *commit,
+                                    const int64_t *last_new_index,
+                                    int64_t *commit_out, hipStream_t stream);

@@ -1,113 +1,8 @@
 // rq_kernels.hip -- gfx950 (MI355X) kernels of the batched Raft quorum engine,
-// 32-bit layout: the quorum round (rq_round_impl.h instantiated for int32_t),
-// the AppendEntries consistency batch and the follower commit clamp.
-#include "rq_round_impl.h"
-
-#include <limits.h>
-
-namespace {
-
-// ---------------------------------------------------------------------------
-// AppendEntries consistency batch: one thread per group; all plane loads of
-// the group's slots are issued before the dependent log gathers.
-//   stepdown : term > cur, cur' = max(cur, term)                 (raft.go:142, :219-221)
-//   reach    : !(term < cur')                                    (:145-147)
-//   success  : reach && log[prevLogIndex].TermNum == prevLogTerm (:151-153)
-//   prevLogIndex outside the follower's log is an index panic in Go: status
-//   bit, no success.
-// Leader bookkeeping for the reply (Raft Fig. 2; the reference only declares
-// nextIndex/matchIndex, raft.go:60-68): success -> match = prev + n_new,
-// next = match + 1; rejected at the log check -> next = max(next - 1, 1);
-// rejected for a stale term -> unchanged.
-// ---------------------------------------------------------------------------
-// NMAX = compile-time slot bound (the loop over slots is fully unrolled so that
-// every plane load of a group is in flight before the first gather).
-template <int NMAX>
-__global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args a) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.G) return;
-    const size_t ld = a.ld;
-    const uint32_t n = a.n;
-    const int32_t lt = __builtin_nontemporal_load(a.leader_term + g);
-    uint32_t act = a.active_mask ? (uint32_t)a.active_mask[g] : 0xFFFFu;
-    act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
-    const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
-    int32_t ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX];
-    uint32_t o0[NMAX], o1[NMAX];
-#pragma unroll
-    for (int p = 0; p < NMAX; p++) {
-        ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
-        if ((act >> p) & 1u) {
-            const size_t s = p * ld + g;
-            ft[p] = __builtin_nontemporal_load(a.follower_term + s);
-            pi[p] = __builtin_nontemporal_load(a.prev_log_index + s);
-            pt[p] = __builtin_nontemporal_load(a.prev_log_term + s);
-            o0[p] = __builtin_nontemporal_load(a.flog_off + s);
-            o1[p] = a.flog_off[s + 1];
-            if (a.n_new) nn[p] = __builtin_nontemporal_load(a.n_new + s);
-            if (a.match_index_io) mi[p] = __builtin_nontemporal_load(a.match_index_io + s);
-            if (a.next_index_io) ni[p] = __builtin_nontemporal_load(a.next_index_io + s);
-        }
-    }
-    uint32_t reach = 0, inb = 0;
-#pragma unroll
-    for (int p = 0; p < NMAX; p++) {
-        const bool r = ((act >> p) & 1u) && lt >= ft[p];
-        const bool in = (uint32_t)pi[p] < (o1[p] - o0[p]);
-        reach |= (uint32_t)r << p;
-        inb |= (uint32_t)in << p;
-        tg[p] = 0;
-        if (r && in) tg[p] = __builtin_nontemporal_load(a.flog_term + ((size_t)o0[p] + (uint32_t)pi[p]));
-    }
-    uint32_t ok = 0, sd = 0, st = 0;
-#pragma unroll
-    for (int p = 0; p < NMAX; p++) {
-        if (!((act >> p) & 1u)) continue;
-        const size_t s = p * ld + g;
-        const bool r = (reach >> p) & 1u, in = (inb >> p) & 1u;
-        const bool success = r && in && tg[p] == pt[p];
-        sd |= (uint32_t)(lt > ft[p]) << p;
-        ok |= (uint32_t)success << p;
-        st |= (r && !in) ? kStLogOob : 0;
-        __builtin_nontemporal_store(max(ft[p], lt), a.follower_term_out + s);
-        if (upd) {
-            int32_t m2 = mi[p], n2 = ni[p];
-            if (success) { m2 = (int32_t)((uint32_t)pi[p] + (uint32_t)nn[p]); n2 = (int32_t)((uint32_t)m2 + 1u); }
-            else if (r) { n2 = n2 > 1 ? n2 - 1 : 1; }
-            if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
-            if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
-        }
-    }
-    __builtin_nontemporal_store((uint16_t)ok, a.success_mask + g);
-    __builtin_nontemporal_store((uint16_t)sd, a.stepdown_mask + g);
-    if (a.status_out) a.status_out[g] = (uint8_t)st;
-}
-
-// raft.go:172-176 elementwise
-__global__ __launch_bounds__(kBlock) void rq_follower_clamp_kernel(
-        uint64_t count, const int32_t *lc, const int32_t *ci, const int32_t *ln,
-        int32_t *out, int vec_ok) {
-    const uint64_t i0 = ((uint64_t)blockIdx.x * kBlock + threadIdx.x) * 4;
-    if (i0 >= count) return;
-    int32_t a[4], b[4], c[4], r[4];
-    const bool full = vec_ok && i0 + 4 <= count;
-    const int valid = full ? 4 : (int)min((uint64_t)4, count - i0);
-    if (full) {
-        ld_i32<4, false, true>(lc + i0, 4, a);
-        ld_i32<4, false, true>(ci + i0, 4, b);
-        ld_i32<4, false, true>(ln + i0, 4, c);
-    } else {
-        ld_i32<4, false, false>(lc + i0, valid, a);
-        ld_i32<4, false, false>(ci + i0, valid, b);
-        ld_i32<4, false, false>(ln + i0, valid, c);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) r[k] = a[k] > b[k] ? min(a[k], c[k]) : b[k];
-    if (full) st_i32<4, false, true>(out + i0, 4, r);
-    else st_i32<4, false, false>(out + i0, valid, r);
-}
-
-}  // namespace
+// 32-bit layout: the quorum round (rq_round_impl.h), the AppendEntries
+// consistency batch and the follower commit clamp (rq_append_impl.h)
+// instantiated for int32_t.
+#include "rq_append_impl.h"
 
 hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, int what,
                            int variant, hipStream_t stream) {
@@ -115,35 +10,11 @@ hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, in
 }
 
 hipError_t rq_launch_append_check(const rq_append_args &a, hipStream_t stream) {
-    if (a.G == 0) return hipSuccess;
-    if (a.G > 0x7FFFFFFFu || a.ld < a.G || a.n < 1 || a.n > 16) return hipErrorInvalidValue;
-    const uint32_t block = 128;
-    const dim3 grid((a.G + block - 1) / block), blk(block);
-    switch (a.n) {
-    case 1: hipLaunchKernelGGL(rq_append_check_kernel<1>, grid, blk, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL(rq_append_check_kernel<2>, grid, blk, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL(rq_append_check_kernel<3>, grid, blk, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL(rq_append_check_kernel<4>, grid, blk, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL(rq_append_check_kernel<5>, grid, blk, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL(rq_append_check_kernel<6>, grid, blk, 0, stream, a); break;
-    case 7: hipLaunchKernelGGL(rq_append_check_kernel<7>, grid, blk, 0, stream, a); break;
-    case 8: hipLaunchKernelGGL(rq_append_check_kernel<8>, grid, blk, 0, stream, a); break;
-    case 9: hipLaunchKernelGGL(rq_append_check_kernel<9>, grid, blk, 0, stream, a); break;
-    default: hipLaunchKernelGGL(rq_append_check_kernel<16>, grid, blk, 0, stream, a); break;
-    }
-    return hipGetLastError();
+    return launch_append_check_impl<int32_t>(a, stream);
 }
 
 hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,
                                     const int32_t *commit, const int32_t *last_new_index,
                                     int32_t *commit_out, hipStream_t stream) {
-    if (count == 0) return hipSuccess;
-    const int vec_ok = aligned_to(leader_commit, 16) && aligned_to(commit, 16) &&
-                       aligned_to(last_new_index, 16) && aligned_to(commit_out, 16);
-    const uint64_t threads = (count + 3) / 4;
-    const uint64_t grid = (threads + kBlock - 1) / kBlock;
-    if (grid > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(rq_follower_clamp_kernel, dim3((uint32_t)grid), dim3(kBlock), 0, stream,
-                       count, leader_commit, commit, last_new_index, commit_out, vec_ok);
-    return hipGetLastError();
+    return launch_follower_clamp_impl<int32_t>(count, leader_commit, commit, last_new_index, commit_out, stream);
 }

@@ -210,23 +210,33 @@ class QuorumEngine:
         res.commit = cout
         return res
 
-    def follower_clamp(self, leader_commit, commit, last_new_index):
-        lc = np.ascontiguousarray(leader_commit, dtype=np.int32).ravel()
-        ci = np.ascontiguousarray(commit, dtype=np.int32).ravel()
-        ln = np.ascontiguousarray(last_new_index, dtype=np.int32).ravel()
+    def follower_clamp(self, leader_commit, commit, last_new_index, wide=False):
+        """wide=True: int64 arrays through rq_follower_clamp64."""
+        dt = np.int64 if wide else np.int32
+        lc = np.ascontiguousarray(leader_commit, dtype=dt).ravel()
+        ci = np.ascontiguousarray(commit, dtype=dt).ravel()
+        ln = np.ascontiguousarray(last_new_index, dtype=dt).ravel()
         if not (lc.size == ci.size == ln.size):
             raise ValueError("follower_clamp arrays must have equal length")
-        out = np.zeros(lc.size, np.int32)
+        out = np.zeros(lc.size, dt)
+        if wide:
+            vp = lambda a: C.c_void_p(a.ctypes.data)
+            self._check(self._l.rq_follower_clamp64(self._h, lc.size, vp(lc), vp(ci), vp(ln), vp(out)),
+                        "rq_follower_clamp64")
+            return out
         self._check(self._l.rq_follower_clamp(self._h, lc.size, _p(lc, i32p), _p(ci, i32p),
                                               _p(ln, i32p), _p(out, i32p)), "rq_follower_clamp")
         return out
 
     def append_check(self, follower_term, leader_term, prev_log_index, prev_log_term,
                      flog_off, flog_term, n_new=None, match_index=None, next_index=None,
-                     active_mask=None, G=None):
+                     active_mask=None, G=None, wide=False):
         """AppendEntries consistency batch.  Returns a dict with follower_term,
         success_mask, stepdown_mask, status and (if given) updated match_index /
-        next_index copies."""
+        next_index copies.  wide=True: int64 planes through rq_append_check64."""
+        if wide:
+            return self._append_check64(follower_term, leader_term, prev_log_index, prev_log_term,
+                                        flog_off, flog_term, n_new, match_index, next_index, active_mask, G)
         ft = _plane(follower_term, "follower_term")
         n, ld = ft.shape
         G = ld if G is None else G
@@ -249,6 +259,30 @@ class QuorumEngine:
                                      _p(out["success_mask"], u16p), _p(out["stepdown_mask"], u16p),
                                      pp(mi, i32p), pp(ni, i32p), _p(out["status"], u8p))
         self._check(rc, "rq_append_check")
+        return out
+
+    def _append_check64(self, follower_term, leader_term, prev_log_index, prev_log_term,
+                        flog_off, flog_term, n_new, match_index, next_index, active_mask, G):
+        c64 = lambda a: np.ascontiguousarray(a, dtype=np.int64)
+        ft = c64(follower_term)
+        n, ld = ft.shape
+        G = ld if G is None else G
+        pi, pt, lt = c64(prev_log_index), c64(prev_log_term), _vec(leader_term, np.int64, "leader_term", G)
+        off = _vec(flog_off, np.uint32, "flog_off", n * ld + 1)
+        arena = c64(flog_term)
+        if arena.size == 0:
+            arena = np.zeros(1, np.int64)
+        opt = lambda a: None if a is None else c64(a).copy()
+        nn, mi, ni = opt(n_new), opt(match_index), opt(next_index)
+        am = None if active_mask is None else _vec(active_mask, np.uint16, "active_mask", G)
+        out = dict(follower_term=ft.copy(), success_mask=np.zeros(G, np.uint16),
+                   stepdown_mask=np.zeros(G, np.uint16), status=np.zeros(G, np.uint8),
+                   match_index=mi, next_index=ni)
+        vp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        rc = self._l.rq_append_check64(self._h, G, n, ld, vp(am), vp(ft), vp(lt), vp(pi), vp(pt), vp(nn),
+                                       vp(off), vp(arena), vp(out["follower_term"]), vp(out["success_mask"]),
+                                       vp(out["stepdown_mask"]), vp(mi), vp(ni), vp(out["status"]))
+        self._check(rc, "rq_append_check64")
         return out
 
     # -- wide layout (int64 planes) -------------------------------------------

@@ -74,6 +74,8 @@ def lib():
         l.orc_follower_clamp.argtypes = [C.c_uint64, i32p, i32p, i32p, i32p]
         l.orc_append_check.argtypes = [u32, u32, u32, u16p, i32p, i32p, i32p, i32p, i32p, u32p, i32p,
                                        i32p, u16p, u16p, i32p, i32p, u8p]
+        l.orc_follower_clamp64.argtypes = [C.c_uint64] + [C.c_void_p] * 4
+        l.orc_append_check64.argtypes = [u32, u32, u32] + [C.c_void_p] * 14
         l.orc_round64.argtypes = [C.c_int, u32, u32, u32] + [C.c_void_p] * 20
         l.orc_bench_build.argtypes = [u32, u32, u32, i32p, i32p, i32p, u32p, i32p, i32p, i32p, i32p,
                                       i32p, i32p]
@@ -213,6 +215,36 @@ def append_check(follower_term, leader_term, prev_log_index, prev_log_term, flog
                                 _p(out.follower_term, i32p), _p(out.success_mask, u16p),
                                 _p(out.stepdown_mask, u16p), pp(mi, i32p), pp(ni, i32p),
                                 _p(out.status, u8p))
+    assert rc == 0, rc
+    return out
+
+
+def follower_clamp64(leader_commit, commit, last_new_index):
+    lc = _c(leader_commit, np.int64).ravel(); ci = _c(commit, np.int64).ravel()
+    ln = _c(last_new_index, np.int64).ravel()
+    out = np.zeros(lc.size, np.int64)
+    vp = lambda a: C.c_void_p(a.ctypes.data)
+    assert lib().orc_follower_clamp64(lc.size, vp(lc), vp(ci), vp(ln), vp(out)) == 0
+    return out
+
+
+def append_check64(follower_term, leader_term, prev_log_index, prev_log_term, flog_off, flog_term,
+                   n_new=None, match_index=None, next_index=None, active_mask=None, G=None):
+    ft = _c(follower_term, np.int64); n, ld = ft.shape; G = ld if G is None else G
+    pi = _c(prev_log_index, np.int64); pt = _c(prev_log_term, np.int64); lt = _c(leader_term, np.int64)
+    off = _c(flog_off, np.uint32); arena = _c(flog_term, np.int64)
+    if arena.size == 0:
+        arena = np.zeros(1, np.int64)
+    opt = lambda a: None if a is None else _c(a, np.int64).copy()
+    nn, mi, ni = opt(n_new), opt(match_index), opt(next_index)
+    am = None if active_mask is None else _c(active_mask, np.uint16)
+    out = Result(follower_term=ft.copy(), success_mask=np.zeros(G, np.uint16),
+                 stepdown_mask=np.zeros(G, np.uint16), status=np.zeros(G, np.uint8),
+                 match_index=mi, next_index=ni)
+    vp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+    rc = lib().orc_append_check64(G, n, ld, vp(am), vp(ft), vp(lt), vp(pi), vp(pt), vp(nn), vp(off), vp(arena),
+                                  vp(out.follower_term), vp(out.success_mask), vp(out.stepdown_mask),
+                                  vp(mi), vp(ni), vp(out.status))
     assert rc == 0, rc
     return out
 

@@ -338,3 +338,98 @@ def test_gpu_wide_full_size_1m_by_5(dev):
     assert np.array_equal(r64["commit"][sl], exp.commit)
     assert np.array_equal(r64["elected"][sl], exp.elected)
     assert np.array_equal(r64["voter_term"][:, sl], exp.voter_term)
+
+
+# ---------------------------------------------------------------------------
+# AppendEntries consistency batch and follower clamp in the wide layout
+# ---------------------------------------------------------------------------
+APPEND_PLANES = ("follower_term", "prev_log_index", "prev_log_term", "n_new", "match_index", "next_index")
+
+
+def widen_append(b, term_shift=0):
+    """int64 image of a gen_append batch; term_shift moves every term (follower,
+    leader, prevLogTerm, log terms) up without changing any comparison."""
+    w = synth.Batch(b)
+    for k in APPEND_PLANES + ("leader_term", "flog_term"):
+        w[k] = np.asarray(b[k]).astype(np.int64)
+    for k in ("follower_term", "leader_term", "prev_log_term", "flog_term"):
+        w[k] = w[k] + term_shift
+    return w
+
+
+def append_call(fn, w, full=True, **extra):
+    kw = dict(n_new=w.n_new, match_index=w.match_index, next_index=w.next_index,
+              active_mask=w.active_mask, G=w.G) if full else dict(G=w.G)
+    kw.update(extra)
+    return fn(w.follower_term, w.leader_term, w.prev_log_index, w.prev_log_term, w.flog_off, w.flog_term, **kw)
+
+
+def assert_append_equal(got, exp, G, full, term_shift=0):
+    assert np.array_equal(got["follower_term"][:, :G], exp["follower_term"][:, :G].astype(np.int64) + term_shift)
+    for f in ("success_mask", "stepdown_mask", "status"):
+        assert np.array_equal(got[f][:G], exp[f][:G]), f
+    if full:
+        assert np.array_equal(got["match_index"][:, :G], exp["match_index"][:, :G])
+        assert np.array_equal(got["next_index"][:, :G], exp["next_index"][:, :G])
+
+
+@pytest.mark.parametrize("n", [1, 3, 5, 9, 16])
+def test_oracle64_append_check_and_clamp_equal_compact_oracle(n):
+    for adv in (False, True):
+        b = synth.gen_append(3000, n, seed=3 * n, adversarial=adv)
+        exp = append_call(o.append_check, b)
+        for shift in (0, 1 << 40):
+            assert_append_equal(append_call(o.append_check64, widen_append(b, shift)), exp, b.G, True, shift)
+    rng = np.random.default_rng(n)
+    lc, ci, ln = (rng.integers(-5, 50, 1000) for _ in range(3))
+    assert np.array_equal(o.follower_clamp64(lc, ci, ln), o.follower_clamp(lc, ci, ln))
+    big = 1 << 45
+    assert np.array_equal(o.follower_clamp64(lc + big, ci + big, ln + big), o.follower_clamp(lc, ci, ln).astype(np.int64) + big)
+
+
+def wide_append_kats(fn):
+    """prevLogIndex values that alias a valid slot in their low 32 bits must be out of range."""
+    n, G = 3, 1
+    off = np.arange(0, 2 * n + 1, 2, dtype=np.uint32)
+    flog = np.tile(np.array([0, 1], np.int64) + (1 << 40), n)
+    ft = np.full((n, G), (1 << 40) + 1, np.int64)
+    pi = np.array([[1], [(1 << 32) + 1], [-1]], np.int64)
+    pt = np.full((n, G), (1 << 40) + 1, np.int64)
+    r = fn(ft, [(1 << 40) + 2], pi, pt, off, flog, n_new=np.full((n, G), 2, np.int64),
+           match_index=np.zeros((n, G), np.int64), next_index=np.full((n, G), 5, np.int64))
+    assert r["success_mask"][0] == 0b001 and r["stepdown_mask"][0] == 0b111 and r["status"][0] == 1
+    assert r["follower_term"][:, 0].tolist() == [(1 << 40) + 2] * 3
+    assert r["match_index"][:, 0].tolist() == [3, 0, 0] and r["next_index"][:, 0].tolist() == [4, 4, 4]
+
+
+def test_oracle64_append_kats():
+    wide_append_kats(o.append_check64)
+
+
+@pytest.mark.gpu
+def test_gpu_wide_append_kats(engine):
+    wide_append_kats(lambda *a, **k: engine.append_check(*a, wide=True, **k))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 7, 9, 16])
+def test_gpu_wide_append_check(engine, n):
+    for G, ld in ((1, 1), (65, 68), (5000, 5000), (30011, 30080)):
+        for adv in (False, True):
+            b = synth.gen_append(G, n, seed=7 * n + G, ld=ld, adversarial=adv)
+            w = widen_append(b, 1 << 40)
+            for full in (True, False):
+                got = append_call(engine.append_check, w, full, wide=True)
+                exp = append_call(o.append_check64, w, full)
+                assert_append_equal(got, exp, G, full)
+
+
+@pytest.mark.gpu
+def test_gpu_wide_follower_clamp(engine):
+    rng = np.random.default_rng(3)
+    for count in (1, 3, 4, 5, 1023, 100003):
+        lc, ci, ln = (rng.integers(-5, 50, count) + (1 << 44) for _ in range(3))
+        assert np.array_equal(engine.follower_clamp(lc, ci, ln, wide=True), o.follower_clamp64(lc, ci, ln))
+    ext = np.array([I64MIN, -1, 0, 1, I64MAX], np.int64)
+    lc, ci, ln = (a.ravel() for a in np.meshgrid(ext, ext, ext))
+    assert np.array_equal(engine.follower_clamp(lc, ci, ln, wide=True), o.follower_clamp64(lc, ci, ln))
