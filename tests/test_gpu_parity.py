@@ -322,6 +322,47 @@ def test_full_size_1m_by_5(engine):
     assert np.array_equal(c2, got.commit)
 
 
+def test_full_size_8m_by_5_sharded_equals_unsharded(dev):
+    """8M groups x 5 peers (the 8-GPU configuration's total) on one GPU: one launch
+    over all groups against eight block-partitioned shard launches (what eight
+    ranks would run), bit for bit, plus size-independent properties; the last
+    shard is also checked against the oracle."""
+    from raft_amd.device import DeviceBatch
+    from raft_amd.sharded import shard_bounds
+    G, n, R = 8 << 20, 5, 8
+    b = synth.gen_fused(G, n, seed=77)
+    whole = DeviceBatch(b)
+    dev.fused_round(whole)
+    w = whole.results()
+    del whole
+    off = b.log_off.astype(np.int64)
+    for r in range(R):
+        g0, g1 = shard_bounds(G, R, r)
+        sb = synth.Batch(b)
+        sb["G"], sb["ld"] = g1 - g0, g1 - g0
+        for k in ("match", "voter_term", "voted_for", "last_log_term"):
+            sb[k] = np.ascontiguousarray(b[k][:, g0:g1])
+        for k in ("commit", "leader_term", "cand_term", "cand_id"):
+            sb[k] = b[k][g0:g1].copy()
+        sb["log_term"] = b.log_term[off[g0]:off[g1]].copy()
+        sb["log_off"] = (off[g0:g1 + 1] - off[g0]).astype(np.uint32)
+        d = DeviceBatch(sb)
+        dev.fused_round(d)
+        s = d.results()
+        for f in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
+            assert np.array_equal(s[f], w[f][g0:g1]), (f, r)
+        assert np.array_equal(s["voter_term"], w["voter_term"][:, g0:g1]), r
+        assert np.array_equal(s["elected_bits"], w["elected_bits"][g0 // 64:g1 // 64]), r
+        if r == R - 1:
+            exp = o.fused_round(*sb.fused_args())
+            assert np.array_equal(s["commit"], exp.commit) and np.array_equal(s["elected"], exp.elected)
+            assert np.array_equal(s["voter_term"], exp.voter_term)
+    N = np.sort(b.match, axis=0)[2]
+    assert (w["commit"] >= b.commit).all() and ((w["commit"] == b.commit) | (w["commit"] == N)).all()
+    assert (w["voter_term"] == np.maximum(b.voter_term, b.cand_term[None, :])).all()
+    assert 0.2 < w["elected"].mean() < 0.9 and 0.1 < (w["commit"] != b.commit).mean() < 0.6
+
+
 # ---------------------------------------------------------------------------
 # AppendEntries consistency batch (raft.go:142-153) + leader reply bookkeeping
 # ---------------------------------------------------------------------------
