@@ -6,7 +6,7 @@ ARCH    ?= gfx950
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC     = raft_amd/csrc
 
-all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so
+all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h $(CSRC)/rq_append_impl.h include/rq.h
 	@mkdir -p build
@@ -23,7 +23,11 @@ raft_amd/libraft_host.so: $(HOST)/raft_host.cpp $(HOST)/raft_host_capi.cpp $(HOS
 oracle/librq_oracle.so: oracle/raft_oracle.c oracle/raft_oracle.h
 	$(CC) -O2 -std=c11 -fPIC -shared -Wall -Wextra -pthread $< -o $@
 
+# the C-ABI from plain C (no HIP headers, no torch)
+examples/rq_cli: examples/rq_cli.c include/rq.h raft_amd/librq.so
+	$(CC) -O2 -std=c11 -Wall -Wextra -Iinclude $< -Lraft_amd -lrq -Wl,-rpath,'$$ORIGIN/../raft_amd' -o $@
+
 clean:
-	rm -rf build raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so
+	rm -rf build raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli
 
 .PHONY: all clean

@@ -1,0 +1,72 @@
+"""examples/rq_cli: the C-ABI driven from a plain C program in its own process
+(no Python, no torch, the system HIP runtime), fed with the committed
+known-answer vectors and a seeded batch, checked against the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle_lib as o
+from raft_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "examples", "rq_cli")
+KATS = json.load(open(os.path.join(ROOT, "tests", "golden", "kats.json")))
+
+
+def run_cli(mode, b):
+    G, n = int(b["G"]), int(b["n"])
+    parts = ["%d %d" % (G, n)]
+    for k in ("match", "commit", "leader_term", "log_off", "log_term", "voter_term", "voted_for",
+              "last_log_term", "cand_term", "cand_id"):
+        a = np.asarray(b[k])
+        a = a[:, :G] if a.ndim == 2 else a
+        parts.append(" ".join(str(int(x)) for x in a.ravel()))
+    p = subprocess.run([CLI, mode], input="\n".join(parts) + "\n", capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    rows = [np.array(line.split(), dtype=np.int64) for line in p.stdout.strip().split("\n")]
+    assert len(rows) == n + 6
+    return dict(commit=rows[0], voter_term=np.stack(rows[1:1 + n]), grant_mask=rows[1 + n],
+                stepdown_mask=rows[2 + n], elected=rows[3 + n], max_term=rows[4 + n], status=rows[5 + n])
+
+
+def test_cli_is_built_and_refuses_bad_input():
+    assert os.access(CLI, os.X_OK), "run `make`"
+    p = subprocess.run([CLI, "host"], input="0 0\n", capture_output=True, text=True, timeout=30)
+    assert p.returncode == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["host", "device"])
+def test_cli_known_answers_and_seeded_batch(mode):
+    # the commit and tally vectors side by side in one 5-slot batch
+    ck = [k for k in KATS["commit"] if len(k["match"]) == 5]
+    tk = [k for k in KATS["tally"] if k["n"] == 5]
+    G = min(len(ck), len(tk))
+    log_terms = [k["log_terms"] for k in ck[:G]]
+    b = synth.Batch(
+        G=G, n=5, ld=G,
+        match=np.array([k["match"] for k in ck[:G]], np.int32).T.copy(),
+        commit=np.array([k["commit"] for k in ck[:G]], np.int32),
+        leader_term=np.array([k["leader_term"] for k in ck[:G]], np.int32),
+        log_off=np.concatenate([[0], np.cumsum([len(t) for t in log_terms])]).astype(np.uint32),
+        log_term=np.concatenate(log_terms).astype(np.int32),
+        voter_term=np.array([[v["cur"] for v in k["voters"]] for k in tk[:G]], np.int32).T.copy(),
+        voted_for=np.array([[v["voted_for"] for v in k["voters"]] for k in tk[:G]], np.int32).T.copy(),
+        last_log_term=np.array([[v["last_log_term"] for v in k["voters"]] for k in tk[:G]], np.int32).T.copy(),
+        cand_term=np.array([k["term"] for k in tk[:G]], np.int32),
+        cand_id=np.array([k["cand"] for k in tk[:G]], np.int32))
+    r = run_cli(mode, b)
+    assert r["commit"].tolist() == [k["expect"] for k in ck[:G]]
+    assert [bool(s & 1) for s in r["status"]] == [k["oob"] for k in ck[:G]]
+    assert [bool(x) for x in r["elected"]] == [k["expect"]["elected"] for k in tk[:G]]
+    assert r["max_term"].tolist() == [k["expect"]["max_term"] for k in tk[:G]]
+    assert [bin(int(m)).count("1") for m in r["grant_mask"]] == [k["expect"]["votes"] for k in tk[:G]]
+    # a seeded adversarial batch against the oracle
+    b = synth.gen_adversarial(3001, 5, seed=8)
+    r = run_cli(mode, b)
+    exp = o.fused_round(*b.fused_args())
+    for f in ("commit", "voter_term", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
+        assert np.array_equal(r[f], exp[f].astype(np.int64)), f
