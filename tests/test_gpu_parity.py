@@ -514,6 +514,8 @@ def test_commit_summary_widths(dev, variant, bits):
             assert res["summary_escapes"] == int((~fit).sum()), (kind, G, base_kind)
             # nothing is written past the summary's last word
             assert bool((buf[summary_buffer_bytes(G, bits):] == 0xAB).all())
+    assert dev._l.rq_engine_set_summary_width(dev._h, 5) == -1        # only 16, 8 and 4 exist
+    assert dev._l.rq_engine_set_summary_width(None, 8) == -1
     dev.set_summary_width(16)
 
 
