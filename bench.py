@@ -51,10 +51,11 @@ def parse():
     ap.add_argument("--ld-pad", type=int, default=256,
                     help="plane stride = groups + pad (elements): keeps the slot planes off one power-of-two stride")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the summary all-gather")
-    ap.add_argument("--summary", choices=["u4", "u8", "u16", "i32"], default="u8",
+    ap.add_argument("--summary", choices=["auto", "u4", "u8", "u16", "i32"], default="auto",
                     help="commit summary on the wire: u4/u8 = the round's commitIndex advance in 4/8 bits "
                          "(offset from the input commitIndex, all ones = escape), u16 = 16-bit offset from 0, "
-                         "i32 = the full vector")
+                         "i32 = the full vector; auto = u8 for the fused workload (advances below 16), u16 "
+                         "for the mixed one (logs of up to 4096 entries)")
     ap.add_argument("--rounds-per-exchange", type=int, default=4,
                     help="summaries of this many consecutive rounds travel in one all-gather")
     ap.add_argument("--exchange-impl", choices=["auto", "native", "torch"], default="torch",
@@ -133,6 +134,8 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.summary == "auto":
+        args.summary = "u8" if args.workload == "fused" else "u16"
     G, n, S = args.groups, args.peers, max(1, args.sets)
     eng = DeviceEngine(dev_index)
     exchange = use_dist and not args.no_exchange

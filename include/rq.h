@@ -233,7 +233,9 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  * the other half of that summary in 16 bits per group: commit'[g] -
  * summary_base[g] (summary_base NULL = 0) when that lies in [0, 65535), else
  * the escape value 65535, in which case *summary_escapes (if not NULL) is
- * incremented and the receiver must fetch the full commit vector; the host
+ * incremented (exact up to 65536, it stops growing soon after: the count tells
+ * a host that its window is wrong, the escape values themselves tell the
+ * receivers which groups) and the receiver must fetch the full commit vector; the host
  * moves summary_base forward before offsets reach the window's end.
  * rq_engine_set_summary_width narrows the summary further for launches and
  * plans made afterwards on that engine: 8 = one byte per group (escape 255),

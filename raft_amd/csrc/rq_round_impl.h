@@ -250,7 +250,8 @@ __device__ __forceinline__ T gather_term(const T *p) {
 // whole wave is convergent.
 template <int V, bool NTS, bool FULL, typename T>
 __device__ __forceinline__ uint32_t store_commit_summary(const rq_round_args_t<T> &a, uint32_t g0, int valid,
-                                                         const T (&co)[V], const T (&cm)[V]) {
+                                                         const T (&co)[V], const T (&cm)[V],
+                                                         uint32_t &escapes_out) {
     const uint32_t bits = a.summary_bits;
     const uint32_t escape = (1u << bits) - 1u;
     const bool base_is_input = a.summary_base == a.commit;
@@ -270,8 +271,25 @@ __device__ __forceinline__ uint32_t store_commit_summary(const rq_round_args_t<T
     }
     if (bits == 16) st_u16<V, NTS, FULL>(a.commit_lo16 + g0, valid, lo);
     else if (bits == 8) st_u8<V, NTS, FULL>(reinterpret_cast<uint8_t *>(a.commit_lo16) + g0, valid, lo);
-    if (escapes && a.summary_escapes) atomicAdd(a.summary_escapes, escapes);
+    escapes_out = escapes;      // summed over the wave by count_escapes(): one atomic per wave
     return nibbles;
+}
+
+// Adds the wave's groups that did not fit the summary window to the caller's
+// counter with one atomic per wave (a counter hit by every escaping thread
+// serialises in L2: 19k escapes in a 1M-group launch cost 100 us that way).
+// The count is exact up to kEscapeCountCap and stops growing soon after: a width
+// that most groups do not fit is a configuration error the host needs to see,
+// not to measure, and must not slow the round down.
+// Must be reached by every lane of the wave.
+constexpr uint32_t kEscapeCountCap = 1u << 16;
+__device__ __forceinline__ void count_escapes(uint32_t escapes, uint32_t *counter) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) escapes += __shfl_xor(escapes, o, 64);
+    if ((threadIdx.x & 63) == 0 && escapes) {
+        if (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < kEscapeCountCap)
+            atomicAdd(counter, escapes);
+    }
 }
 
 // 4-bit summary: 16 groups per 64-bit word (group g in bits 4*(g%16) of word
@@ -290,6 +308,7 @@ __device__ __forceinline__ void pack_nibbles(uint32_t field, uint64_t g0, uint32
 struct round_fields {
     uint32_t elected;   // bit k: group g0+k elected
     uint32_t nibbles;   // 4 bits per group: 4-bit commit summary
+    uint32_t escapes;   // groups of this thread whose summary offset did not fit
 };
 
 // Slot of log[N] inside the group's arena slice, as an unsigned number: with a
@@ -377,7 +396,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     }
 
     // ---- vote: per-slot predicate, tally ----
-    uint32_t el_field = 0, nib_field = 0;
+    uint32_t el_field = 0, nib_field = 0, esc_field = 0;
     if constexpr (DO_VOTE) {
         uint32_t gm[V], sm[V], el[V];
         T mx[V];
@@ -417,10 +436,10 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
         }
         st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
-        if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm);
+        if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm, esc_field);
     }
     if (a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return round_fields{el_field, nib_field};
+    return round_fields{el_field, nib_field, esc_field};
 }
 
 template <int N, int V, int WHAT, int FLAGS, typename T>
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
         }
         __syncthreads();
     }
-    round_fields f{0, 0};
+    round_fields f{0, 0, 0};
     if (g0 + V <= a.G)
         f = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, lds_log, lds_seg0);
     else if (g0 < a.G)
@@ -458,6 +477,7 @@ __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
     if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
         if (a.commit_lo16 && a.summary_bits == 4)
             pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));
+        if (a.commit_lo16 && a.summary_escapes) count_escapes(f.escapes, a.summary_escapes);
     }
 }
 
@@ -555,7 +575,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
     // loads are all issued before any of them is consumed, and chunk 0 is issued
     // before the commit side's sort so that it is in flight behind it.
     constexpr int kChunk = 8;
-    uint32_t el_field = 0, nib_field = 0;
+    uint32_t el_field = 0, nib_field = 0, esc_field = 0;
     T ct[V], ci[V], mx[V];
     uint32_t gm[V], sm[V];
     T cvt[kChunk][V], cvf[kChunk][V], cll[kChunk][V];
@@ -704,11 +724,11 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         }
         if (in_range) {
             st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
-            if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm);
+            if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm, esc_field);
         }
     }
     if (in_range && a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return round_fields{el_field, nib_field};
+    return round_fields{el_field, nib_field, esc_field};
 }
 
 template <int MMAX, int V, int WHAT, int FLAGS, typename T>
@@ -729,6 +749,7 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
     if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
         if (a.commit_lo16 && a.summary_bits == 4)
             pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));
+        if (a.commit_lo16 && a.summary_escapes) count_escapes(f.escapes, a.summary_escapes);
     }
 }
 
