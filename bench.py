@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--groups", type=int, default=1 << 20, help="groups per GPU")
+    ap.add_argument("--total-groups", type=int, default=0,
+                    help="strong scaling: this many groups in total, block-partitioned over the ranks "
+                         "(8388608 = the 8M-group configuration); overrides --groups")
     ap.add_argument("--peers", type=int, default=5)
     ap.add_argument("--sets", type=int, default=12,
                     help="rotating input+output sets; 12 x ~176 MB keeps reads AND writes out of the 256 MB Infinity Cache")
@@ -134,6 +137,13 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    strong = args.total_groups > 0
+    if strong:
+        from raft_amd.sharded import shard_bounds
+        if args.total_groups % world:
+            raise SystemExit("--total-groups must be a multiple of the number of ranks")
+        g0, g1 = shard_bounds(args.total_groups, world, rank)
+        args.groups = g1 - g0
     if args.summary == "auto":
         args.summary = "u8" if args.workload == "fused" else "u16"
     G, n, S = args.groups, args.peers, max(1, args.sets)
@@ -248,7 +258,7 @@ def main():
             "metric": "quorum decisions/sec at 1M groups x 5 peers (1/8 GPU); % of HBM peak",
             "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int64" if args.layout == "i64" else "int32", "data": "synthetic",
             "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
                        "resident_mb_per_gpu": round(resident_mb, 1),
