@@ -11,6 +11,8 @@ progressively more of its parts:
   sideonly / mainwait / sidewait   one ingredient of the fences at a time
   value  the fences made of hipStreamWriteValue32 / hipStreamWaitValue32 on 8-byte
          signal memory instead of events
+  graph-copy / graph-rccl   a whole cycle of 12 rounds and its exchanges captured
+         into one graph and replayed
   *-q    the slot's next round skips its wait when the event is already complete
 Prints microseconds per step for each."""
 import os
@@ -88,9 +90,40 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e6
 
+    def run_graph(mode):
+        """One whole cycle of S rounds (fences + copy or RCCL all-gather per R rounds)
+        captured into a graph and replayed."""
+        def cycle():
+            for s in range(S):
+                slot = s // R
+                eng.fused_round(sets[s])
+                if s % R == R - 1:
+                    side.wait_stream(torch.cuda.current_stream(dev))
+                    with torch.cuda.stream(side):
+                        if mode == "graph-copy":
+                            allb[slot].copy_(local[slot], non_blocking=True)
+                        else:
+                            dist.all_gather_into_tensor(allb[slot], local[slot])
+            torch.cuda.current_stream(dev).wait_stream(side)      # rejoin before the capture ends
+        cycle()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cycle()
+        for _ in range(warm // S):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps // S):
+            g.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / (steps // S * S) * 1e6
+
     def run(mode):
         if mode == "value":
             return run_value()
+        if mode.startswith("graph"):
+            return run_graph(mode)
         def step(i):
             s = i % S
             slot = s // R
@@ -131,7 +164,8 @@ def main():
         torch.cuda.synchronize()
         return (time.perf_counter() - t0) / steps * 1e6
 
-    for mode in ("none", "sideonly", "mainwait", "sidewait", "record", "fence", "copy", "rccl", "value"):
+    for mode in ("none", "sideonly", "mainwait", "sidewait", "record", "fence", "copy", "rccl", "value",
+                 "graph-copy", "graph-rccl"):
         print("%-6s %.2f us/step" % (mode, run(mode)), flush=True)
     eng.close()
     dist.destroy_process_group()
