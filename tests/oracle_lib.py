@@ -107,8 +107,10 @@ def commit_advance(match, commit, leader_term, log_off, log_term, G=None, old_ma
     N > commitIndex test are shift-invariant), the result shifted back."""
     if log_base is not None:
         base = _c(log_base, np.int32).astype(np.int64)
-        m64 = _c(match, np.int32).astype(np.int64) - base[None, :]
-        c64 = _c(commit, np.int32).astype(np.int64) - base
+        m64 = _c(match, np.int32).astype(np.int64)
+        m64[:, : base.size] -= base[None, :]              # planes may be wider (ld > G)
+        c64 = _c(commit, np.int32).astype(np.int64)
+        c64[: base.size] -= base[: c64.size]
         assert np.abs(m64).max(initial=0) < 2 ** 31 and np.abs(c64).max(initial=0) < 2 ** 31
         out, st = commit_advance(m64.astype(np.int32), c64.astype(np.int32), leader_term, log_off, log_term,
                                  G, old_mask, new_mask)

@@ -662,6 +662,52 @@ def test_fuzz_shapes_and_variants(dev):
         _check_dev(db.results(), exp, G)
 
 
+def test_fuzz_layouts_windows_and_summaries(dev):
+    """Random combinations of layout (int32 / int64), membership (fixed / masks), log
+    window, summary width and base, kernel build, group count and stride."""
+    import torch
+    from raft_amd.device import DeviceBatch, summary_buffer_bytes
+    rng = np.random.default_rng(77)
+    variants = [0, 1, 2, 4, 0x31, 0x32, 0x131, 0x171, 0x271, 0x274, 0x472]
+    for it in range(48):
+        G = int(rng.integers(1, 2500))
+        wide, joint, window = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        bits = int(rng.choice([0, 4, 8, 16]))
+        variant = int(rng.choice(variants))
+        if joint:
+            b = synth.gen_mixed(G, seed=900 + it)
+            kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
+        else:
+            b = synth.gen_fused(G, int(rng.integers(1, 17)), seed=900 + it, ld=G + int(rng.choice([0, 1, 4, 64])))
+            kw = {}
+        if window:
+            b = synth.window_logs(b, keep_committed=int(rng.integers(0, 3)))
+            kw["log_base"] = b.log_base
+        exp = o.fused_round(*b.fused_args(), G=G, **kw)
+        batch = synth.widen(b)[0] if wide else b
+        skw = {}
+        if bits:
+            base_kind = str(rng.choice(["commit", "zero"]))
+            skw = dict(commit_lo16=torch.zeros(summary_buffer_bytes(G, bits) + 8, dtype=torch.uint8, device="cuda:0"),
+                       summary_escapes=torch.zeros(2, dtype=torch.int32, device="cuda:0"),
+                       summary_bits=bits, summary_base="commit" if base_kind == "commit" else None)
+        db = DeviceBatch(batch, **skw)
+        dev.fused_round(db, variant=variant)
+        res = db.results()
+        case = (it, G, wide, joint, window, bits, hex(variant))
+        mem = member_matrix(b)[:, :G] if joint else np.ones((b.n, G), bool)
+        for f in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
+            assert np.array_equal(res[f][:G].astype(np.int64), exp[f][:G].astype(np.int64)), (f, case)
+        assert np.array_equal(res["voter_term"][:, :G][mem], exp["voter_term"][:, :G][mem]), case
+        if bits:
+            d = exp["commit"].astype(np.int64) - (b.commit[:G] if base_kind == "commit" else 0)
+            esc = (1 << bits) - 1
+            fit = (d >= 0) & (d < esc)
+            assert np.array_equal(res["commit_lo16"], np.where(fit, d, esc).astype(np.uint16)), case
+            assert res["summary_escapes"] == int((~fit).sum()), case
+    dev.set_summary_width(16)
+
+
 def test_two_engines_from_two_threads():
     """Distinct engines may be driven concurrently (one stream and one mutex each)."""
     import threading
