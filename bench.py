@@ -6,9 +6,10 @@ log-term gather) over this rank's 1M groups x 5 peers, inputs resident in HBM.
 Input/output sets rotate (default 12 sets, ~2.1 GB in total: both the reads
 and the 36 MB of writes per step exceed the 256 MB Infinity Cache, which
 otherwise absorbs the writes of up to 5 sets and flatters the number).  With N > 1 ranks the
-groups are sharded (weak scaling: 1M groups per GPU) and every step also
-all-gathers the commit/elected summary over RCCL, overlapped with the next
-step's kernel.
+groups are sharded (weak scaling: 1M groups per GPU; --total-groups T instead
+block-partitions T groups over the ranks, strong scaling, e.g. 8388608) and the
+commit/elected summary of every step is all-gathered over RCCL (one collective
+per 4 steps by default), overlapped with the following steps' kernels.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
