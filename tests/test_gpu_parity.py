@@ -601,6 +601,18 @@ def test_plane_offsets_beyond_4_gib(dev):
         vt_out.zero_()
 
 
+def test_reused_pinned_output_buffers(engine):
+    b = synth.gen_adversarial(5003, 5, seed=4, ld=5120)
+    out = engine.round_buffers(5, 5120, G=5003)
+    for seed in (4, 5):                      # second call overwrites the first one's results
+        b = synth.gen_adversarial(5003, 5, seed=seed, ld=5120)
+        got = engine.fused_round(*b.fused_args(), G=5003, out=out)
+        assert got is out
+        exp = o.fused_round(*b.fused_args(), G=5003)
+        assert np.array_equal(got.commit, exp.commit)
+        assert_vote_equal(got, exp, 5003)
+
+
 def test_pinned_host_buffers(engine):
     b = synth.gen_fused(30000, 5, seed=44)
     pinned = [engine.pinned_like(a) for a in b.fused_args()]
