@@ -6,7 +6,7 @@ ARCH    ?= gfx950
 HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
 CSRC     = raft_amd/csrc
 
-all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli
+all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli examples/rq_bench
 
 build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h $(CSRC)/rq_append_impl.h include/rq.h
 	@mkdir -p build
@@ -24,10 +24,10 @@ oracle/librq_oracle.so: oracle/raft_oracle.c oracle/raft_oracle.h
 	$(CC) -O2 -std=c11 -fPIC -shared -Wall -Wextra -pthread $< -o $@
 
 # the C-ABI from plain C (no HIP headers, no torch)
-examples/rq_cli: examples/rq_cli.c include/rq.h raft_amd/librq.so
+examples/rq_%: examples/rq_%.c include/rq.h raft_amd/librq.so
 	$(CC) -O2 -std=c11 -Wall -Wextra -Iinclude $< -Lraft_amd -lrq -Wl,-rpath,'$$ORIGIN/../raft_amd' -o $@
 
 clean:
-	rm -rf build raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli
+	rm -rf build raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli examples/rq_bench
 
 .PHONY: all clean

@@ -70,3 +70,16 @@ def test_cli_known_answers_and_seeded_batch(mode):
     exp = o.fused_round(*b.fused_args())
     for f in ("commit", "voter_term", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
         assert np.array_equal(r[f], exp[f].astype(np.int64)), f
+
+
+@pytest.mark.gpu
+def test_plain_c_benchmark_runs():
+    """examples/rq_bench: device memory, a plan and the timed loop through the C-ABI alone."""
+    exe = os.path.join(ROOT, "examples", "rq_bench")
+    p = subprocess.run([exe, "65536", "5", "4", "60", "12"], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    f = p.stdout.split()
+    assert [int(x) for x in f[:4]] == [65536, 5, 4, 60]
+    assert float(f[4]) > 0 and float(f[7]) > 0
+    share = float(p.stderr.split("elected")[1].split("%")[0])
+    assert 10 < share < 90                      # the drawn batch elects a plausible share of its groups
