@@ -29,6 +29,9 @@ type roundBuffers[T word] struct {
 	commitOut, voterTermOut, maxTerm                   []T
 	grantMask, stepdownMask                            []uint16
 	elected, status                                    []uint8
+	// groups smaller than slots occupy the low slots; memberMask[g] = 1<<size - 1
+	memberMask []uint16
+	mixed      bool // some group has fewer than slots members: the round needs the masks
 }
 
 // limits of a layout: its largest value, a candidate term no voter reacts to,
@@ -78,6 +81,7 @@ func flatten[T word](d *BatchedDriver, L layout[T]) (*roundBuffers[T], error) {
 	b.grantMask, b.stepdownMask = make([]uint16, G), make([]uint16, G)
 	b.elected, b.status = make([]uint8, G), make([]uint8, G)
 	b.logOff = make([]uint32, G+1)
+	b.memberMask = make([]uint16, G)
 	put := func(dst *T, v int) bool {
 		if !L.fits(v) {
 			return false
@@ -86,15 +90,20 @@ func flatten[T word](d *BatchedDriver, L layout[T]) (*roundBuffers[T], error) {
 		return true
 	}
 	for g, grp := range d.groups {
-		if len(grp.Members) != n {
-			return nil, errors.New("raft: group size differs from the driver's slot count")
+		k := len(grp.Members)
+		if k < 1 || k > n || n > 16 {
+			return nil, errors.New("raft: a group needs 1..slots members (slots <= 16)")
+		}
+		b.memberMask[g] = uint16(1)<<uint(k) - 1
+		if k != n {
+			b.mixed = true
 		}
 		b.commit[g], b.candTerm[g] = L.max, L.belowAll
 		if l := grp.Leader; l != nil {
 			if !put(&b.commit[g], l.commitIndex) || !put(&b.leaderTerm[g], l.currentTerm) {
 				return nil, errRange
 			}
-			for p := 0; p < n && p < len(l.matchIndex); p++ {
+			for p := 0; p < k && p < len(l.matchIndex); p++ {
 				if !put(&b.match[p*G+g], l.matchIndex[p]) {
 					return nil, errRange
 				}
@@ -157,7 +166,8 @@ func apply[T word](d *BatchedDriver, b *roundBuffers[T]) {
 }
 
 // Step runs one fused round and applies it. The compact layout is tried first;
-// if some value does not fit int32 the round runs in the wide layout.
+// if some value does not fit int32 the round runs in the wide layout. Groups
+// of different sizes run through the member-mask round (old = new = members).
 func (d *BatchedDriver) Step() error {
 	b, err := flatten(d, compact)
 	if err == errRange {

@@ -44,22 +44,37 @@ func i64(p []int64) *C.int64_t   { return (*C.int64_t)(unsafe.Pointer(&p[0])) }
 // fusedRound passes only flat scalar slices (no Go pointers inside them), which
 // is what the cgo pointer rules require; librq copies before it returns.
 func (e *rqEngine) fusedRound(b *roundBuffers[int32]) error {
-	rc := C.rq_fused_round(e.h, C.uint32_t(b.groups), C.uint32_t(b.slots), C.uint32_t(b.ld),
-		i32(b.match), i32(b.commit), i32(b.leaderTerm), u32(b.logOff), i32(b.logTerm),
-		i32(b.voterTerm), i32(b.votedFor), i32(b.lastLogTerm), i32(b.candTerm), i32(b.candID),
-		i32(b.commitOut), i32(b.voterTermOut), u16(b.grantMask), u16(b.stepdownMask),
-		u8(b.elected), i32(b.maxTerm), u8(b.status))
+	var rc C.int
+	if b.mixed {
+		rc = C.rq_fused_round_joint(e.h, C.uint32_t(b.groups), C.uint32_t(b.slots), C.uint32_t(b.ld),
+			u16(b.memberMask), u16(b.memberMask),
+			i32(b.match), i32(b.commit), i32(b.leaderTerm), u32(b.logOff), i32(b.logTerm),
+			i32(b.voterTerm), i32(b.votedFor), i32(b.lastLogTerm), i32(b.candTerm), i32(b.candID),
+			i32(b.commitOut), i32(b.voterTermOut), u16(b.grantMask), u16(b.stepdownMask),
+			u8(b.elected), i32(b.maxTerm), u8(b.status))
+	} else {
+		rc = C.rq_fused_round(e.h, C.uint32_t(b.groups), C.uint32_t(b.slots), C.uint32_t(b.ld),
+			i32(b.match), i32(b.commit), i32(b.leaderTerm), u32(b.logOff), i32(b.logTerm),
+			i32(b.voterTerm), i32(b.votedFor), i32(b.lastLogTerm), i32(b.candTerm), i32(b.candID),
+			i32(b.commitOut), i32(b.voterTermOut), u16(b.grantMask), u16(b.stepdownMask),
+			u8(b.elected), i32(b.maxTerm), u8(b.status))
+	}
 	if rc != C.RQ_OK {
 		return errors.New("rq_fused_round: " + C.GoString(C.rq_strerror(rc)))
 	}
 	return nil
 }
 
-// round64 is the same round in the wide layout (rq_round64): fixed-size groups
-// (no masks), full logs (no window base), both decisions in one launch.
+// round64 is the same round in the wide layout (rq_round64): member masks only
+// when the groups differ in size, full logs (no window base), both decisions in
+// one launch.
 func (e *rqEngine) round64(b *roundBuffers[int64]) error {
+	var mask *C.uint16_t
+	if b.mixed {
+		mask = u16(b.memberMask)
+	}
 	rc := C.rq_round64(e.h, C.RQ_ROUND_COMMIT|C.RQ_ROUND_VOTE,
-		C.uint32_t(b.groups), C.uint32_t(b.slots), C.uint32_t(b.ld), nil, nil,
+		C.uint32_t(b.groups), C.uint32_t(b.slots), C.uint32_t(b.ld), mask, mask,
 		i64(b.match), i64(b.commit), i64(b.leaderTerm), u32(b.logOff), i64(b.logTerm), nil,
 		i64(b.voterTerm), i64(b.votedFor), i64(b.lastLogTerm), i64(b.candTerm), i64(b.candID),
 		i64(b.commitOut), i64(b.voterTermOut), u16(b.grantMask), u16(b.stepdownMask),

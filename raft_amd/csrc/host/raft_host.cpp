@@ -127,12 +127,16 @@ int BatchedDriver::FlattenT(const std::vector<Group> &groups, uint32_t n, RoundB
     b.grantMask.assign(G, 0); b.stepdownMask.assign(G, 0);
     b.elected.assign(G, 0); b.status.assign(G, 0);
     b.logOff.assign((size_t)G + 1, 0);
+    b.memberMask.assign(G, 0);
     for (uint32_t g = 0; g < G; g++) {
         const Group &grp = groups[g];
-        if (grp.Members.size() != n) return kDriverShape;
+        const uint32_t k = (uint32_t)grp.Members.size();
+        if (k < 1 || k > n || n > RQ_MAX_SLOTS) return kDriverShape;
+        b.memberMask[g] = (uint16_t)((1u << k) - 1u);
+        if (k != n) b.mixed = true;
         if (const Node *l = grp.Leader) {
             if (!narrow(l->commitIndex, b.commit[g]) || !narrow(l->currentTerm, b.leaderTerm[g])) return kDriverRange;
-            for (uint32_t p = 0; p < n && p < l->matchIndex.size(); p++)
+            for (uint32_t p = 0; p < k && p < l->matchIndex.size(); p++)
                 if (!narrow(l->matchIndex[p], b.match[(size_t)p * G + g])) return kDriverRange;
             for (const Entry &e : l->log) {
                 T t;
@@ -145,7 +149,7 @@ int BatchedDriver::FlattenT(const std::vector<Group> &groups, uint32_t n, RoundB
         if (const Node *c = grp.Candidate) {
             if (!narrow(c->currentTerm, b.candTerm[g]) || !narrow(c->id, b.candId[g])) return kDriverRange;
         }
-        for (uint32_t p = 0; p < n; p++) {
+        for (uint32_t p = 0; p < k; p++) {
             const Node *m = grp.Members[p];
             const size_t i = (size_t)p * G + g;
             if (!narrow(m->currentTerm, b.voterTerm[i]) || !narrow(m->votedFor, b.votedFor[i])) return kDriverRange;
@@ -166,7 +170,7 @@ void BatchedDriver::ApplyT(std::vector<Group> &groups, const RoundBuffersT<T> &b
         Group &grp = groups[g];
         Node *leader_before = grp.Leader;
         if (grp.Candidate) {
-            for (uint32_t p = 0; p < b.slots; p++) {
+            for (uint32_t p = 0; p < b.slots && p < grp.Members.size(); p++) {
                 Node *m = grp.Members[p];
                 m->currentTerm = b.voterTermOut[(size_t)p * b.ld + g];
                 if ((b.stepdownMask[g] >> p) & 1u) m->nodeType = Follower;  // raft.go:221
@@ -214,7 +218,8 @@ int BatchedDriver::Step(int device) {
         if (rc != kDriverOk) return rc == kDriverRange ? RQ_E_RANGE : RQ_E_ARG;
         rc = EnsureEngine(device, w.groups, w.slots, w.logTerm.size());
         if (rc != RQ_OK) return rc;
-        rc = rq_round64(engine_, RQ_ROUND_COMMIT | RQ_ROUND_VOTE, w.groups, w.slots, w.ld, nullptr, nullptr,
+        const uint16_t *mask = w.mixed ? w.memberMask.data() : nullptr;
+        rc = rq_round64(engine_, RQ_ROUND_COMMIT | RQ_ROUND_VOTE, w.groups, w.slots, w.ld, mask, mask,
                         w.match.data(), w.commit.data(), w.leaderTerm.data(), w.logOff.data(),
                         w.logTerm.data(), nullptr, w.voterTerm.data(), w.votedFor.data(),
                         w.lastLogTerm.data(), w.candTerm.data(), w.candId.data(), w.commitOut.data(),
@@ -228,11 +233,19 @@ int BatchedDriver::Step(int device) {
     if (rc != kDriverOk) return RQ_E_ARG;
     rc = EnsureEngine(device, b.groups, b.slots, b.logTerm.size());
     if (rc != RQ_OK) return rc;
-    rc = rq_fused_round(engine_, b.groups, b.slots, b.ld, b.match.data(), b.commit.data(),
-                        b.leaderTerm.data(), b.logOff.data(), b.logTerm.data(), b.voterTerm.data(),
-                        b.votedFor.data(), b.lastLogTerm.data(), b.candTerm.data(), b.candId.data(),
-                        b.commitOut.data(), b.voterTermOut.data(), b.grantMask.data(),
-                        b.stepdownMask.data(), b.elected.data(), b.maxTerm.data(), b.status.data());
+    if (b.mixed)
+        rc = rq_fused_round_joint(engine_, b.groups, b.slots, b.ld, b.memberMask.data(), b.memberMask.data(),
+                                  b.match.data(), b.commit.data(), b.leaderTerm.data(), b.logOff.data(),
+                                  b.logTerm.data(), b.voterTerm.data(), b.votedFor.data(),
+                                  b.lastLogTerm.data(), b.candTerm.data(), b.candId.data(),
+                                  b.commitOut.data(), b.voterTermOut.data(), b.grantMask.data(),
+                                  b.stepdownMask.data(), b.elected.data(), b.maxTerm.data(), b.status.data());
+    else
+        rc = rq_fused_round(engine_, b.groups, b.slots, b.ld, b.match.data(), b.commit.data(),
+                            b.leaderTerm.data(), b.logOff.data(), b.logTerm.data(), b.voterTerm.data(),
+                            b.votedFor.data(), b.lastLogTerm.data(), b.candTerm.data(), b.candId.data(),
+                            b.commitOut.data(), b.voterTermOut.data(), b.grantMask.data(),
+                            b.stepdownMask.data(), b.elected.data(), b.maxTerm.data(), b.status.data());
     if (rc != RQ_OK) return rc;
     Apply(b);
     last_step_wide_ = false;

@@ -103,6 +103,9 @@ struct RoundBuffersT {
     std::vector<T> commitOut, voterTermOut, maxTerm;
     std::vector<uint16_t> grantMask, stepdownMask;
     std::vector<uint8_t> elected, status;
+    // groups smaller than `slots` occupy the low slots; memberMask[g] = (1 << size) - 1
+    std::vector<uint16_t> memberMask;
+    bool mixed = false;   // some group has fewer than `slots` members: the round needs the masks
 };
 typedef RoundBuffersT<int32_t> RoundBuffers;
 typedef RoundBuffersT<int64_t> RoundBuffers64;
@@ -111,6 +114,7 @@ enum : int { kDriverOk = 0, kDriverRange = -2, kDriverShape = -1 };
 
 class BatchedDriver {
 public:
+    // slots = the largest group size; smaller groups are allowed (1..slots members).
     BatchedDriver(std::vector<Group> groups, uint32_t slots) : groups_(std::move(groups)), slots_(slots) {}
     ~BatchedDriver();
     // AoS -> SoA.  A value the layout cannot hold gives kDriverRange and leaves
@@ -124,7 +128,8 @@ public:
     void Apply(const RoundBuffers64 &b);
     // Flatten -> one fused round on `device` -> Apply.  The compact layout is
     // tried first; if some value does not fit int32 the round runs in the wide
-    // layout instead.  Returns an RQ_* code.
+    // layout instead.  Groups of different sizes run through the member-mask
+    // (joint) round with old = new = the group's members.  Returns an RQ_* code.
     int Step(int device);
     bool LastStepWide() const { return last_step_wide_; }
     std::vector<Group> &Groups() { return groups_; }

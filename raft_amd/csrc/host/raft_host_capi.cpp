@@ -39,6 +39,26 @@ rh_cluster *rh_cluster_new(uint32_t G, uint32_t n) {
     return c;
 }
 
+// Groups of different sizes: group g has sizes[g] members (1..n) in its low slots;
+// the remaining slots of the group hold no node.
+rh_cluster *rh_cluster_new_sizes(uint32_t G, uint32_t n, const uint32_t *sizes) {
+    auto *c = new rh_cluster();
+    c->G = G; c->n = n;
+    c->nodes.assign((size_t)G * n, nullptr);
+    std::vector<Group> groups(G);
+    for (uint32_t g = 0; g < G; g++) {
+        std::vector<Node *> peers;
+        for (uint32_t p = 0; p < sizes[g] && p < n; p++) {
+            Node *x = NewNode((int64_t)p, peers, nullptr);
+            peers.push_back(x);
+            c->nodes[(size_t)g * n + p] = x;
+        }
+        groups[g].Members = peers;
+    }
+    c->driver.reset(new BatchedDriver(std::move(groups), n));
+    return c;
+}
+
 void rh_cluster_free(rh_cluster *c) { delete c; }
 
 static Node *at(rh_cluster *c, uint32_t g, uint32_t p) { return c->nodes[(size_t)g * c->n + p]; }
@@ -64,7 +84,7 @@ void rh_node_get(rh_cluster *c, uint32_t g, uint32_t p, int64_t *out) {
 int rh_node_get_leader_arrays(rh_cluster *c, uint32_t g, uint32_t p, int64_t *next, int64_t *match) {
     Node *x = at(c, g, p);
     if (!x->Inspect().hasLeaderArrays) return 0;
-    for (uint32_t i = 0; i < c->n; i++) { next[i] = x->NextIndex()[i]; match[i] = x->MatchIndex()[i]; }
+    for (uint32_t i = 0; i < c->n && i < x->NextIndex().size(); i++) { next[i] = x->NextIndex()[i]; match[i] = x->MatchIndex()[i]; }
     return 1;
 }
 
@@ -90,7 +110,7 @@ void rh_group_roles(rh_cluster *c, uint32_t g, int leader_slot, int candidate_sl
 void rh_group_get_roles(rh_cluster *c, uint32_t g, int *leader_slot, int *candidate_slot) {
     Group &grp = c->driver->Groups()[g];
     *leader_slot = *candidate_slot = -1;
-    for (uint32_t p = 0; p < c->n; p++) {
+    for (uint32_t p = 0; p < c->n && p < grp.Members.size(); p++) {
         if (grp.Members[p] == grp.Leader) *leader_slot = (int)p;
         if (grp.Members[p] == grp.Candidate) *candidate_slot = (int)p;
     }
@@ -138,6 +158,12 @@ int rh_driver_flatten(rh_cluster *c, int32_t *match, int32_t *commit, int32_t *l
     if (b.logTerm.size() > log_term_cap) return -3;
     std::memcpy(log_term, b.logTerm.data(), b.logTerm.size() * 4);
     return 0;
+}
+
+// member masks of the last rh_driver_flatten ([G]); returns 1 if the groups differ in size
+int rh_driver_member_masks(rh_cluster *c, uint16_t *mask) {
+    std::memcpy(mask, c->last.memberMask.data(), c->last.memberMask.size() * 2);
+    return c->last.mixed ? 1 : 0;
 }
 
 // Apply outputs (layout of rq_fused_round) to the objects; uses the shapes of the last Flatten.

@@ -22,6 +22,9 @@ def lib():
         l = C.CDLL(PATH)
         l.rh_cluster_new.restype = C.c_void_p
         l.rh_cluster_new.argtypes = [C.c_uint32, C.c_uint32]
+        l.rh_cluster_new_sizes.restype = C.c_void_p
+        l.rh_cluster_new_sizes.argtypes = [C.c_uint32, C.c_uint32, u32p]
+        l.rh_driver_member_masks.argtypes = [C.c_void_p, u16p]
         l.rh_cluster_free.argtypes = [C.c_void_p]; l.rh_cluster_free.restype = None
         l.rh_node_seed.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32] + [C.c_int64] * 4
         l.rh_node_seed.restype = None
@@ -54,9 +57,15 @@ FIELDS = ("id", "nodeType", "currentTerm", "votedFor", "logLen", "commitIndex", 
 
 
 class Cluster:
-    def __init__(self, G, n):
+    def __init__(self, G, n, sizes=None):
+        """sizes: members per group (1..n each); None = every group has n members."""
         self.l = lib(); self.G, self.n = G, n
-        self.h = C.c_void_p(self.l.rh_cluster_new(G, n))
+        if sizes is None:
+            self.h = C.c_void_p(self.l.rh_cluster_new(G, n))
+        else:
+            a = np.ascontiguousarray(sizes, dtype=np.uint32)
+            assert a.size == G
+            self.h = C.c_void_p(self.l.rh_cluster_new_sizes(G, n, a.ctypes.data_as(u32p)))
 
     def close(self):
         if self.h:
@@ -121,6 +130,10 @@ class Cluster:
                                       p(b["last_log_term"], i32p), p(b["cand_term"], i32p),
                                       p(b["cand_id"], i32p), C.byref(used))
         b["log_term"] = b["log_term"][: used.value]
+        if rc == 0:
+            mask = np.zeros(G, np.uint16)
+            b["mixed"] = bool(self.l.rh_driver_member_masks(self.h, mask.ctypes.data_as(u16p)))
+            b["member_mask"] = mask
         return rc, b
 
     def flatten64(self, log_cap=1 << 20):

@@ -229,3 +229,97 @@ def test_step_falls_back_to_the_wide_layout():
             assert (c.get_roles(g)[0] == cand) == bool(r.elected[g])
     finally:
         c.close()
+
+
+def _build_mixed(G, seed):
+    """Groups of 3..9 members whose object state equals a gen_mixed batch without joint
+    configurations; returns (cluster, batch, sizes)."""
+    b = synth.gen_mixed(G, seed=seed, joint_frac=0.0)
+    sizes = np.array([bin(int(m)).count("1") for m in b.old_mask[:G]], np.uint32)
+    n = int(sizes.max())
+    c = h.Cluster(G, n, sizes=sizes)
+    for g in range(G):
+        k = int(sizes[g])
+        lead, cand = (int(b.cand_id[g]) + 1) % k, int(b.cand_id[g]) % k
+        lo, hi = int(b.log_off[g]), int(b.log_off[g + 1])
+        for p in range(k):
+            logs = [int(b.last_log_term[p, g])] if b.last_log_term[p, g] != synth.LOG_EMPTY else []
+            if p == lead:
+                logs = [int(x) for x in b.log_term[lo:hi]]
+            c.seed(g, p, int(b.voter_term[p, g]), int(b.voted_for[p, g]), h.FOLLOWER, 0, logs)
+        c.become(g, lead, 0)
+        c.seed(g, lead, int(b.leader_term[g]), int(b.voted_for[lead, g]), h.LEADER, int(b.commit[g]))
+        c.set_match(g, lead, [int(x) for x in b.match[:k, g]])
+        c.seed(g, cand, int(b.cand_term[g]), int(b.voted_for[cand, g]), h.CANDIDATE, 0)
+        c.roles(g, leader=lead, candidate=cand)
+    return c, b, sizes
+
+
+def test_flatten_groups_of_different_sizes():
+    G = 400
+    c, b, sizes = _build_mixed(G, seed=6)
+    try:
+        rc, f = c.flatten(log_cap=1 << 22)
+        assert rc == 0 and f["mixed"]
+        assert np.array_equal(f["member_mask"], (1 << sizes.astype(np.int64)) - 1)
+        n = f["match"].shape[0]
+        mem = (np.arange(n)[:, None] < sizes[None, :])
+        assert np.array_equal(f["match"][mem], b.match[:n, :G][mem])
+        assert (f["match"][~mem] == 0).all() and (f["voted_for"][~mem] == -1).all()
+        assert (f["last_log_term"][~mem] == synth.LOG_EMPTY).all()
+        assert np.array_equal(f["log_off"], b.log_off[:G + 1])
+        for g in range(G):
+            k = int(sizes[g])
+            assert c.get_roles(g) == ((int(b.cand_id[g]) + 1) % k, int(b.cand_id[g]) % k)
+            assert len(c.leader_arrays(g, c.get_roles(g)[0])[1]) == c.n
+    finally:
+        c.close()
+
+
+def test_apply_with_groups_of_different_sizes():
+    """Flatten -> the oracle's member-mask round -> Apply, all on the CPU."""
+    G = 300
+    c, b, sizes = _build_mixed(G, seed=7)
+    try:
+        rc, f = c.flatten(log_cap=1 << 22)
+        assert rc == 0
+        r = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                          f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"],
+                          old_mask=f["member_mask"], new_mask=f["member_mask"])
+        roles_before = [c.get_roles(g) for g in range(G)]
+        c.apply(r)
+        for g in range(G):
+            lead, cand = roles_before[g]
+            for p in range(int(sizes[g])):
+                assert c.get(g, p)["currentTerm"] == r.voter_term[p, g]
+            assert c.get(g, lead)["commitIndex"] == r.commit[g]
+            assert (c.get_roles(g)[0] == cand) == bool(r.elected[g])
+            if r.elected[g]:
+                assert len(c.leader_arrays(g, cand)[0]) == c.n      # hook pads to n; node holds sizes[g]
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_step_with_groups_of_different_sizes():
+    """Step() on 3..9-member groups runs the member-mask round; the objects end up where
+    the oracle's joint round (old = new = members) on the flattened image says."""
+    G = 1500
+    c, b, sizes = _build_mixed(G, seed=8)
+    try:
+        rc, f = c.flatten(log_cap=1 << 23)
+        assert rc == 0 and f["mixed"]
+        r = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                          f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"],
+                          old_mask=f["member_mask"], new_mask=f["member_mask"])
+        roles_before = [c.get_roles(g) for g in range(G)]
+        assert c.step(0) == 0 and not c.last_step_wide()
+        for g in range(G):
+            lead, cand = roles_before[g]
+            for p in range(int(sizes[g])):
+                assert c.get(g, p)["currentTerm"] == r.voter_term[p, g]
+            assert c.get(g, lead)["commitIndex"] == r.commit[g]
+            assert (c.get_roles(g)[0] == cand) == bool(r.elected[g])
+        assert 0.05 < r.elected.mean() < 0.95
+    finally:
+        c.close()
