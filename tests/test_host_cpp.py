@@ -323,3 +323,68 @@ def test_step_with_groups_of_different_sizes():
         assert 0.05 < r.elected.mean() < 0.95
     finally:
         c.close()
+
+
+def _scenario_three_node_groups(step):
+    """64 three-node groups through a whole term: election (batched tally), one client
+    entry replicated with AppendEntriesRPC inside its non-panicking domain (slot-0
+    sentinel, followers pre-extended, raft.go:158-161), commit advance (batched), and
+    the follower clamp on the next heartbeat.  `step(cluster)` runs one batched round."""
+    G, n = 64, 3
+    c = h.Cluster(G, n)
+    try:
+        for g in range(G):
+            for p in range(n):
+                c.seed(g, p, 0, -1, h.FOLLOWER, 0, [0])
+            c.become(g, 0, 2)                                   # BecomeCandidate: no term bump (:126-130)
+            c.seed(g, 0, 1, -1, h.CANDIDATE, 0)                 # ... the host bumps the term
+            c.roles(g, leader=-1, candidate=0)
+        step(c)
+        for g in range(G):
+            assert c.get_roles(g) == (0, -1)                    # elected, no longer a candidate
+            assert [c.get(g, p)["currentTerm"] for p in range(n)] == [1, 1, 1]
+            assert c.get(g, 0)["nodeType"] == h.LEADER and c.get(g, 1)["nodeType"] == h.FOLLOWER
+            nx, mt = c.leader_arrays(g, 0)
+            assert nx == [2, 2, 2] and mt == [0, 0, 0]          # :108, :116 (log holds the sentinel only)
+        # one client entry at slot 1 of every leader; followers that are reachable replicate it
+        for g in range(G):
+            c.seed(g, 0, 1, -1, h.LEADER, 0, [0, 1])
+            reach = {0: (1, 2), 1: (1,), 2: (2,), 3: ()}[g % 4]
+            match = [1, 0, 0]
+            for p in reach:
+                c.seed(g, p, 1, -1, h.FOLLOWER, 0, [0, 0])     # pre-extended: slot 1 exists (:159)
+                rc, tr, ok = c.append_entries(g, p, 1, 0, 0, 0, [(1, 1)], 0)
+                assert (rc, tr, ok) == (0, 1, True)
+                match[p] = 1
+            c.set_match(g, 0, match)
+        step(c)
+        for g in range(G):
+            expect = 0 if g % 4 == 3 else 1                     # a majority of 3 needs one follower
+            assert c.get(g, 0)["commitIndex"] == expect
+            assert c.get_roles(g) == (0, -1)
+        # heartbeat carrying leaderCommit: followers clamp to min(leaderCommit, last new index) (:172-176)
+        for g in range(G):
+            lc = c.get(g, 0)["commitIndex"]
+            for p in {0: (1, 2), 1: (1,), 2: (2,), 3: ()}[g % 4]:
+                rc, tr, ok = c.append_entries(g, p, 1, 0, 0, 0, [(1, 1)], lc)
+                assert (rc, ok) == (0, True) and c.get(g, p)["commitIndex"] == lc
+    finally:
+        c.close()
+
+
+def _oracle_step(c):
+    rc, f = c.flatten()
+    assert rc == 0 and not f["mixed"]
+    c.apply(o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                          f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"]))
+
+
+def test_three_node_groups_through_a_term_on_cpu():
+    _scenario_three_node_groups(_oracle_step)
+
+
+@pytest.mark.gpu
+def test_three_node_groups_through_a_term_on_gpu():
+    def gpu_step(c):
+        assert c.step(0) == 0
+    _scenario_three_node_groups(gpu_step)
