@@ -292,3 +292,19 @@ class DeviceEngine:
                                        p(o["max_term"]), p(o["status"]),
                                        p(o["elected_bits"]) if want_bits else None)
         self._check(rc, "rq_vote_tally_dev")
+
+    def append_check(self, t, G, n, ld):
+        """Enqueue the AppendEntries consistency batch on device tensors (rq_append_check_dev,
+        or rq_append_check64_dev when the planes are int64).  t: dict of tensors with the
+        C-ABI names; active_mask, n_new, match_index, next_index and status may be absent.
+        follower_term_out may be the follower_term tensor itself (in-place terms);
+        match_index / next_index are updated in place."""
+        wide = t["follower_term"].dtype == torch.int64
+        p = lambda k: t[k].data_ptr() if t.get(k) is not None else None
+        fn = self._l.rq_append_check64_dev if wide else self._l.rq_append_check_dev
+        rc = fn(self._h, self._stream(), G, n, ld, p("active_mask"), p("follower_term"), p("leader_term"),
+                p("prev_log_index"), p("prev_log_term"), p("n_new"), p("flog_off"), p("flog_term"),
+                p("follower_term_out"), p("success_mask"), p("stepdown_mask"), p("match_index"),
+                p("next_index"), p("status"))
+        if rc != 0:
+            self._check(rc, "rq_append_check_dev")

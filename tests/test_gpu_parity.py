@@ -421,6 +421,74 @@ def test_replicate_then_commit_closes_the_loop(engine):
     assert np.array_equal(gc, ec) and np.array_equal(gst, est)
 
 
+@pytest.mark.parametrize("wide", [False, True])
+def test_device_resident_replication_rounds(dev, wide):
+    """Six rounds with the leader state resident on the device: every round a fresh
+    AppendEntries batch updates follower terms, matchIndex and nextIndex IN PLACE
+    (rq_append_check_dev), then the commit kernel reads that matchIndex plane and
+    advances commitIndex in place.  The oracle does the same on host arrays."""
+    import torch
+    G, n, ld = 20011, 5, 20096
+    dt, tdt = (np.int64, torch.int64) if wide else (np.int32, torch.int32)
+    SH = (1 << 40) if wide else 0                      # wide: terms beyond int32
+    lead = synth.gen_fused(G, n, seed=3, ld=ld)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    first = synth.gen_append(G, n, seed=100, ld=ld)
+    h_ft = first.follower_term.astype(dt) + SH
+    h_mi, h_ni = first.match_index.astype(dt), first.next_index.astype(dt)
+    h_commit = lead.commit.astype(dt).copy()
+    d_ft, d_mi, d_ni, d_commit = up(h_ft), up(h_mi), up(h_ni), up(h_commit)
+    d_lead = dict(leader_term=up(lead.leader_term.astype(dt) + SH), log_off=up(lead.log_off.view(np.int32)),
+                  log_term=up(lead.log_term.astype(dt) + SH))
+    d_status = torch.zeros(G, dtype=torch.uint8, device="cuda:0")
+    for r in range(6):
+        b = synth.gen_append(G, n, seed=100 + r, ld=ld, adversarial=bool(r % 2))
+        planes = {k: b[k].astype(dt) for k in ("prev_log_index", "n_new")}
+        planes["prev_log_term"] = b.prev_log_term.astype(dt) + SH
+        lt = b.leader_term.astype(dt) + SH
+        flog = b.flog_term.astype(dt) + SH
+        t = dict(active_mask=up(b.active_mask.view(np.int16)), follower_term=d_ft, leader_term=up(lt),
+                 prev_log_index=up(planes["prev_log_index"]), prev_log_term=up(planes["prev_log_term"]),
+                 n_new=up(planes["n_new"]), flog_off=up(b.flog_off.view(np.int32)), flog_term=up(flog),
+                 follower_term_out=d_ft, success_mask=torch.zeros(G, dtype=torch.int16, device="cuda:0"),
+                 stepdown_mask=torch.zeros(G, dtype=torch.int16, device="cuda:0"),
+                 match_index=d_mi, next_index=d_ni, status=torch.zeros(G, dtype=torch.uint8, device="cuda:0"))
+        dev.append_check(t, G, n, ld)
+        # commit over the matchIndex plane the append kernel has just updated
+        p = lambda x: x.data_ptr()
+        if wide:
+            rc = dev._l.rq_round64_dev(dev._h, dev._stream(), 0, 1, G, n, ld, None, None, p(d_mi), p(d_commit),
+                                       p(d_lead["leader_term"]), p(d_lead["log_off"]), p(d_lead["log_term"]), None,
+                                       None, None, None, None, None, p(d_commit), None, None, None, None, None,
+                                       p(d_status), None, None, None, None)
+        else:
+            rc = dev._l.rq_commit_advance_dev(dev._h, dev._stream(), 0, G, n, ld, p(d_mi), p(d_commit),
+                                              p(d_lead["leader_term"]), p(d_lead["log_off"]), p(d_lead["log_term"]),
+                                              p(d_commit), p(d_status), None)
+        assert rc == 0
+        # the same on the host
+        fn = o.append_check64 if wide else o.append_check
+        e = fn(h_ft, lt, planes["prev_log_index"], planes["prev_log_term"], b.flog_off, flog,
+               n_new=planes["n_new"], match_index=h_mi, next_index=h_ni, active_mask=b.active_mask, G=G)
+        h_ft, h_mi, h_ni = e["follower_term"], e["match_index"], e["next_index"]
+        if wide:
+            rr = o.round64(1, match=h_mi, commit=h_commit, leader_term=lead.leader_term.astype(dt) + SH,
+                           log_off=lead.log_off, log_term=lead.log_term.astype(dt) + SH, G=G)
+            h_commit, h_st = rr.commit, rr.status
+        else:
+            h_commit, h_st = o.commit_advance(h_mi, h_commit, lead.leader_term, lead.log_off, lead.log_term, G=G)
+        torch.cuda.synchronize()
+        assert np.array_equal(t["success_mask"].cpu().numpy().view(np.uint16), e["success_mask"]), r
+        assert np.array_equal(t["stepdown_mask"].cpu().numpy().view(np.uint16), e["stepdown_mask"]), r
+        assert np.array_equal(t["status"].cpu().numpy(), e["status"]), r
+        assert np.array_equal(d_status.cpu().numpy(), h_st), r
+        assert np.array_equal(d_commit.cpu().numpy()[:G], h_commit[:G]), r
+    assert np.array_equal(d_ft.cpu().numpy()[:, :G], h_ft[:, :G])
+    assert np.array_equal(d_mi.cpu().numpy()[:, :G], h_mi[:, :G])
+    assert np.array_equal(d_ni.cpu().numpy()[:, :G], h_ni[:, :G])
+    assert (h_commit[:G] != lead.commit[:G]).mean() > 0.05          # the rounds did move commitIndex
+
+
 def test_device_memory_helpers_round_trip(dev):
     """rq_device_alloc / rq_copy_to_device / rq_copy_from_device / rq_device_free,
     and a commit round on memory obtained through them (no torch allocations)."""
