@@ -788,6 +788,42 @@ def test_fuzz_layouts_windows_and_summaries(dev):
     dev.set_summary_width(16)
 
 
+def test_two_streams_on_one_engine(dev):
+    """Device-pointer launches keep no state in the engine: two torch streams drive
+    the same engine handle at the same time on different batches."""
+    import torch
+    from raft_amd.device import DeviceBatch
+    batches = [synth.gen_fused(200003, 5, seed=60 + i) for i in range(4)]
+    exps = [o.fused_round(*b.fused_args()) for b in batches]
+    dbs = [DeviceBatch(b, in_place=True) for b in batches]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    for rep in range(3):                                      # in-place rounds are idempotent after the first
+        for i, db in enumerate(dbs):
+            with torch.cuda.stream(streams[i % 2]):
+                dev.fused_round(db)
+    torch.cuda.synchronize()
+    for db, b, exp in zip(dbs, batches, exps):
+        r = db.results()
+        assert np.array_equal(r["voter_term"], exp["voter_term"]) and np.array_equal(r["elected"], exp["elected"])
+        # commit moved at most once: the second round sees N == commit
+        assert np.array_equal(r["commit"], exp["commit"])
+
+
+def test_comm_argument_errors(dev):
+    import ctypes as C
+    l = dev._l
+    h = C.c_void_p()
+    idbuf = (C.c_uint8 * 128)()
+    assert l.rq_comm_unique_id(None) == -1
+    assert l.rq_comm_create(0, None, 0, 1, 2, C.byref(h)) == -1
+    assert l.rq_comm_create(0, idbuf, 1, 1, 2, C.byref(h)) == -1          # rank >= world
+    assert l.rq_comm_create(0, idbuf, 0, 1, 0, C.byref(h)) == -1          # no slots
+    assert l.rq_comm_destroy(None) == -1 and l.rq_comm_sync(None) == -1
+    assert l.rq_comm_wait(None, None, 0) == -1
+    assert l.rq_comm_allgather(None, None, 0, None, None, 0) == -1
+
+
 def test_two_engines_from_two_threads():
     """Distinct engines may be driven concurrently (one stream and one mutex each)."""
     import threading
