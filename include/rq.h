@@ -321,6 +321,22 @@ int rq_plan_fused_round(rq_engine *e, int variant, int joint,
                         uint8_t *status_out, uint64_t *elected_bits,
                         uint16_t *commit_lo16, const int32_t *summary_base,
                         uint32_t *summary_escapes, const int32_t *log_base, rq_plan **out);
+/* The same for one rq_round64_dev argument set (any `what`, masks optional). */
+int rq_plan_round64(rq_engine *e, int variant, int what,
+                    uint32_t G, uint32_t m, uint32_t ld,
+                    const uint16_t *old_mask, const uint16_t *new_mask,
+                    const int64_t *match, const int64_t *commit,
+                    const int64_t *leader_term, const uint32_t *log_off,
+                    const int64_t *log_term, const int64_t *log_base,
+                    const int64_t *voter_term, const int64_t *voted_for,
+                    const int64_t *voter_last_log_term,
+                    const int64_t *cand_term, const int64_t *cand_id,
+                    int64_t *commit_out, int64_t *voter_term_out,
+                    uint16_t *grant_mask, uint16_t *stepdown_mask,
+                    uint8_t *elected, int64_t *max_term,
+                    uint8_t *status_out, uint64_t *elected_bits,
+                    uint16_t *commit_lo16, const int64_t *summary_base,
+                    uint32_t *summary_escapes, rq_plan **out);
 int rq_plan_launch(rq_plan *p, void *stream);
 int rq_plan_destroy(rq_plan *p);
 

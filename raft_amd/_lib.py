@@ -58,6 +58,7 @@ PROTOTYPES = {
     "rq_append_check64_dev": [vp, vp, u32, u32, u32] + [vp] * 14,
     "rq_round64_dev": [vp, vp, cint, cint, u32, u32, u32] + [vp] * 24,
     "rq_plan_fused_round": [vp, cint, cint, u32, u32, u32] + [vp] * 24 + [C.POINTER(vp)],
+    "rq_plan_round64": [vp, cint, cint, u32, u32, u32] + [vp] * 24 + [C.POINTER(vp)],
     "rq_plan_launch": [vp, vp],
     "rq_plan_destroy": [vp],
     "rq_stream_sync": [vp, vp],

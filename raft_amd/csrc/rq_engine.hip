@@ -15,6 +15,10 @@ struct rq_plan {
     uint32_t n;
     bool joint;
     int variant;
+    // wide plans (rq_plan_round64) use these instead of args
+    bool wide = false;
+    int what = RQ_WHAT_COMMIT | RQ_WHAT_VOTE;
+    rq_round64_args args64;
 };
 
 struct rq_engine {
@@ -903,6 +907,49 @@ int rq_round64_dev(rq_engine *e, void *stream, int variant, int what, uint32_t G
     return dev_launch(e, stream, variant, m, old_mask != nullptr, what, a);
 }
 
+int rq_plan_round64(rq_engine *e, int variant, int what, uint32_t G, uint32_t m,
+                   uint32_t ld, const uint16_t *old_mask, const uint16_t *new_mask,
+                   const int64_t *match, const int64_t *commit, const int64_t *leader_term,
+                   const uint32_t *log_off, const int64_t *log_term, const int64_t *log_base,
+                   const int64_t *voter_term, const int64_t *voted_for,
+                   const int64_t *voter_last_log_term, const int64_t *cand_term,
+                   const int64_t *cand_id, int64_t *commit_out, int64_t *voter_term_out,
+                   uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
+                   int64_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
+                   uint16_t *commit_lo16, const int64_t *summary_base,
+                   uint32_t *summary_escapes, rq_plan **out) {
+    if (!e || !out) return RQ_E_ARG;
+    *out = nullptr;
+    if ((old_mask == nullptr) != (new_mask == nullptr)) return RQ_E_ARG;
+    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (what & ~(RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return RQ_E_ARG;
+    if (m < 1 || m > RQ_MAX_SLOTS || ld < G || G > 0x7FFFFFFFu) return RQ_E_ARG;
+    if ((what & RQ_WHAT_COMMIT) && (!match || !commit || !leader_term || !log_off || !log_term || !commit_out))
+        return RQ_E_ARG;
+    if ((what & RQ_WHAT_VOTE) && (!voter_term || !voted_for || !voter_last_log_term || !cand_term || !cand_id ||
+                                  !voter_term_out || !grant_mask || !stepdown_mask || !elected || !max_term))
+        return RQ_E_ARG;
+    rq_round64_args a;
+    std::memset(&a, 0, sizeof a);
+    a.G = G; a.ld = ld; a.m = m;
+    a.old_mask = old_mask; a.new_mask = new_mask;
+    a.match = match; a.commit = commit; a.leader_term = leader_term;
+    a.log_off = log_off; a.log_term = log_term; a.log_base = log_base;
+    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
+    a.cand_term = cand_term; a.cand_id = cand_id;
+    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
+    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
+    a.status_out = status_out; a.elected_bits = elected_bits;
+    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
+    a.summary_bits = e->summary_bits.load();
+    rq_plan *p = new (std::nothrow) rq_plan();
+    if (!p) return RQ_E_NOMEM;
+    p->engine = e; p->n = m; p->joint = old_mask != nullptr; p->variant = variant;
+    p->wide = true; p->what = what; p->args64 = a;
+    std::memset(&p->args, 0, sizeof p->args);
+    *out = p;
+    return RQ_OK;
+}
+
 int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out) {
     if (!e || !out || bytes == 0 || kind < 0 || kind > 2) return RQ_E_ARG;
     *out = nullptr;
@@ -987,8 +1034,10 @@ int rq_plan_fused_round(rq_engine *e, int variant, int joint, uint32_t G, uint32
         !grant_mask || !stepdown_mask || !elected || !max_term)
         return RQ_E_ARG;
     if (joint && (!old_mask || !new_mask)) return RQ_E_ARG;
-    rq_plan *p = new (std::nothrow) rq_plan{e, a, n, joint != 0, variant};
+    rq_plan *p = new (std::nothrow) rq_plan();
     if (!p) return RQ_E_NOMEM;
+    p->engine = e; p->args = a; p->n = n; p->joint = joint != 0; p->variant = variant;
+    std::memset(&p->args64, 0, sizeof p->args64);
     *out = p;
     return RQ_OK;
 }
@@ -997,8 +1046,9 @@ int rq_plan_launch(rq_plan *p, void *stream) {
     if (!p) return RQ_E_ARG;
     rq_engine *e = p->engine;
     RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = rq_launch_round(p->args, p->n, p->joint, RQ_WHAT_COMMIT | RQ_WHAT_VOTE,
-                                     p->variant, (hipStream_t)stream);
+    hipError_t err = p->wide
+        ? rq_launch_round(p->args64, p->n, p->joint, p->what, p->variant, (hipStream_t)stream)
+        : rq_launch_round(p->args, p->n, p->joint, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, p->variant, (hipStream_t)stream);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;

@@ -248,23 +248,46 @@ class DeviceEngine:
         if rc != 0:
             self._check(rc, "rq_fused_round_dev")
 
-    def round64(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
-        """Enqueue the commit (what & 1) and/or vote (what & 2) decision for a wide
-        (int64) DeviceBatch through rq_round64_dev."""
-        assert b.wide
-        self._match_width(b)
+    def _round64_args(self, b, want_bits, status):
         t, o = b.t, b.o
         p = lambda x: None if x is None else x.data_ptr()
-        rc = self._l.rq_round64_dev(
-            self._h, self._stream(), variant, what, b.G, b.n, b.ld,
-            p(t.get("old_mask")), p(t.get("new_mask")),
-            p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
-            p(t.get("log_base")),
-            p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
-            p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
-            p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
-            p(o["elected_bits"]) if want_bits else None,
-            p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]))
+        return [b.G, b.n, b.ld,
+                p(t.get("old_mask")), p(t.get("new_mask")),
+                p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
+                p(t.get("log_base")),
+                p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
+                p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
+                p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
+                p(o["elected_bits"]) if want_bits else None,
+                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"])]
+
+    def round64(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """Enqueue the commit (what & 1) and/or vote (what & 2) decision for a wide
+        (int64) DeviceBatch: validated once into an rq_plan (rq_plan_round64), then
+        launched with rq_plan_launch."""
+        assert b.wide
+        key = ("w", what, variant, want_bits, status, b.summary_bits)
+        plan = b._args.get(key)
+        if plan is None:
+            import ctypes as C
+            self._match_width(b)
+            plan = C.c_void_p()
+            rc = self._l.rq_plan_round64(self._h, variant, what, *self._round64_args(b, want_bits, status),
+                                         C.byref(plan))
+            if rc != 0:
+                self._check(rc, "rq_plan_round64")
+            b._args[key] = plan
+            b._plans.append((self._l, plan))
+        rc = self._l.rq_plan_launch(plan, self._stream())
+        if rc != 0:
+            self._check(rc, "rq_plan_launch")
+
+    def round64_direct(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """The same through rq_round64_dev (all arguments marshalled on every call)."""
+        assert b.wide
+        self._match_width(b)
+        rc = self._l.rq_round64_dev(self._h, self._stream(), variant, what,
+                                    *self._round64_args(b, want_bits, status))
         if rc != 0:
             self._check(rc, "rq_round64_dev")
 

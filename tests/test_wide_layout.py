@@ -433,3 +433,27 @@ def test_gpu_wide_follower_clamp(engine):
     ext = np.array([I64MIN, -1, 0, 1, I64MAX], np.int64)
     lc, ci, ln = (a.ravel() for a in np.meshgrid(ext, ext, ext))
     assert np.array_equal(engine.follower_clamp(lc, ci, ln, wide=True), o.follower_clamp64(lc, ci, ln))
+
+
+@pytest.mark.gpu
+def test_gpu_wide_plan_equals_direct_launch(dev):
+    """rq_plan_round64 + rq_plan_launch against rq_round64_dev, fixed and joint, every `what`."""
+    from raft_amd.device import DeviceBatch
+    from raft_amd._lib import RqError
+    for b in (synth.gen_fused(50021, 5, seed=15), synth.gen_mixed(20003, seed=16)):
+        w, _ = synth.widen(b, term_shift=1 << 37)
+        exp = o.round64(3, **wide_kwargs(w))
+        for what in (1, 2, 3):
+            d1, d2 = DeviceBatch(w), DeviceBatch(w)
+            for _ in range(2):                       # the second launch reuses the cached plan
+                dev.round64(d1, what)
+            dev.round64_direct(d2, what)
+            r1, r2 = d1.results(), d2.results()
+            for f in OUT_FIELDS:
+                assert np.array_equal(r1[f], r2[f]), (f, what)
+            if what == 3:
+                assert_same(r1, exp, w)
+    import ctypes as C
+    plan = C.c_void_p()
+    assert dev._l.rq_plan_round64(dev._h, 0, 0, 10, 3, 10, *([None] * 24), C.byref(plan)) == -1   # no decision
+    assert dev._l.rq_plan_round64(dev._h, 0, 1, 10, 3, 10, *([None] * 24), C.byref(plan)) == -1   # null planes
