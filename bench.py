@@ -5,20 +5,32 @@ A step = one fused round (RequestVote tally + commitIndex advance with the
 log-term gather) over this rank's 1M groups x 5 peers, inputs resident in HBM.
 Input/output sets rotate (default 12 sets, ~2.1 GB in total: both the reads
 and the 36 MB of writes per step exceed the 256 MB Infinity Cache, which
-otherwise absorbs the writes of up to 5 sets and flatters the number).  With N > 1 ranks the
-groups are sharded (weak scaling: 1M groups per GPU; --total-groups T instead
-block-partitions T groups over the ranks, strong scaling, e.g. 8388608) and the
-commit/elected summary of every step is all-gathered over RCCL (one collective
-per 4 steps by default), overlapped with the following steps' kernels.
+otherwise absorbs the writes of up to 5 sets and flatters the number).  Before
+anything is timed every set's prepared launch is built and one untimed rotation
+over all sets is run, so the --warmup / --steps the caller asks for are honoured
+exactly and no timed step is the first touch of its buffers.
+
+With N > 1 ranks the groups are sharded (weak scaling: 1M groups per GPU;
+--total-groups T instead block-partitions T groups over the ranks, strong
+scaling, e.g. 8388608) and the commit/elected summary of every step is
+all-gathered over RCCL (one collective per 4 steps by default), overlapped with
+the following steps' kernels.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+Started without a launcher (no WORLD_SIZE in the environment) and with
+--gpus N > 1, this process starts the N rank processes itself -- before it
+touches torch or the GPU -- and relays rank 0's line.
+
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak
+KERNEL_SOURCES = ("raft_amd/csrc/rq_round_impl.h", "raft_amd/csrc/rq_kernels.h", "raft_amd/csrc/rq_kernels.hip")
 
 
 def alg_bytes_per_group(n, what="fused", layout="i32"):
@@ -35,6 +48,16 @@ def alg_bytes_per_group(n, what="fused", layout="i32"):
     commit = e * n + 3 * e + 4 + e   # n match + commit + leaderTerm + gathered term + logOff ; commit'
     vote = 4 * e * n + 3 * e + 5     # 3n planes + candTerm + candId ; n voterTerm' + maxTerm + 2 + 2 + 1
     return {"commit": commit, "vote": vote, "fused": commit + vote}[what]
+
+
+def kernel_source_hash():
+    """Fingerprint of the round kernels' source: a PMC traffic figure taken from a
+    profile is only attached to a run of the same kernel source."""
+    h = hashlib.sha1()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
 def parse():
@@ -66,11 +89,19 @@ def parse():
                     help="summary all-gather through librq's own RCCL communicator or torch.distributed")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise torch.distributed and run the summary all-gather even with one rank")
+    ap.add_argument("--consume", action="store_true",
+                    help="with the exchange: every gathered summary is also decoded on the device "
+                         "(commit offsets added to this rank's replica of all ranks' commitIndex)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the secondary measurements (wide layout, mixed/joint workload, 32-bit log arena)")
     ap.add_argument("--log-window", type=int, default=-1,
                     help=">= 0: keep only the uncommitted suffix of every log plus this many committed "
                          "entries on the device (log_base window); -1: full logs (the default workload)")
+    ap.add_argument("--log-term-bits", type=int, choices=[0, 8, 16, 32], default=0,
+                    help="width of the log-term arena entries; 0 = the narrowest the batch's terms fit "
+                         "(what a host keeping the arena resident would choose), 32 = the plain int32 arena")
     ap.add_argument("--layout", choices=["i32", "i64"], default="i32",
                     help="i64: the wide layout (rq_round64_dev), values shifted beyond the int32 range")
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
@@ -78,6 +109,37 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """--gpus N without a launcher: this process (which has not touched torch or the
+    GPU) starts the N ranks as children with the rendezvous in their environment,
+    relays rank 0's JSON line and exits non-zero if any rank does."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        out = subprocess.PIPE if r == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
+    line, _ = procs[0].communicate()
+    codes = []
+    deadline = time.time() + 120            # the other ranks end with rank 0; do not wait for a wedged one
+    for p in procs:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()
+            codes.append(p.wait())
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
+        sys.exit(1)
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    sys.exit(0)
 
 
 def cpu_baseline(args, synth):
@@ -103,8 +165,81 @@ def cpu_baseline(args, synth):
                 single_thread_value=out["single"]["value"], host_cpus=os.cpu_count())
 
 
+def timed_launches(torch, device, launch, steps, warmup, preheat):
+    """HIP-event time per launch of launch(i) on the current stream: `preheat`
+    untimed launches (first touch, prepared launches built), `warmup` more, then
+    `steps` timed ones."""
+    for i in range(preheat):
+        launch(i)
+    torch.cuda.synchronize(device)
+    for i in range(warmup):
+        launch(i)
+    torch.cuda.synchronize(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(steps):
+        launch(i)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return e0.elapsed_time(e1) / steps
+
+
+def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
+    """Secondary figures, each a few hundred launches: the same fused round in the
+    wide (int64) layout -- Go's int is 64-bit, raft.go:35-68 --, with the plain
+    32-bit log-term arena, and the mixed 3-9 peer + joint-consensus workload."""
+    import numpy as np
+    out = {}
+    G, n = args.groups, args.peers
+    steps, warmup = 120, 12
+
+    def frac(bytes_per_group, ms):
+        return bytes_per_group * G / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+
+    # plain int32 arena (no narrowing), otherwise the headline workload
+    sets = [DeviceBatch(b, device, log_term_bits=32) for b in host_batches]
+    S = len(sets)
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(sets[i % S]), steps, warmup, S)
+    out["arena_i32"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n), ms), input_sets=S,
+                            note="log-term arena kept as int32 entries")
+    del sets
+    torch.cuda.empty_cache()
+
+    # wide layout on the first sets (8 output sets x 66 MB exceed the Infinity Cache)
+    wide = []
+    for s, b in enumerate(host_batches[:8]):
+        w, _ = synth.widen(b, index_shift=0, term_shift=1 << 41, id_shift=1 << 42, seed=1000 + s)
+        wide.append(DeviceBatch(w, device))
+    S = len(wide)
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(wide[i % S]), steps, warmup, S)
+    out["i64"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n, "fused", "i64"), ms), input_sets=S,
+                      alg_bytes_per_group=alg_bytes_per_group(n, "fused", "i64"),
+                      note="rq_round64_dev, terms and ids shifted beyond 2^41")
+    del wide
+    torch.cuda.empty_cache()
+
+    # mixed 3-9 peers + 10 % joint consensus, Zipf log lengths; one log arena shared by the sets
+    first = synth.gen_mixed(G, seed=500)
+    msets = [DeviceBatch(first, device)]
+    for s in range(1, 8):
+        msets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), device, share_log_with=msets[0]))
+    mem = (first.old_mask | first.new_mask).astype(np.int64)
+    members = float(sum((mem >> p) & 1 for p in range(16)).mean())
+    bpg = 20 * members + 41
+    S = len(msets)
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(msets[i % S]), steps, warmup, S)
+    out["mixed"] = dict(kernel_ms=ms, frac=frac(bpg, ms), input_sets=S, alg_bytes_per_group=bpg,
+                        mean_member_slots=members,
+                        note="mixed 3-9 peers + 10% joint consensus, Zipf(1.2) logs up to 4096 entries")
+    del msets
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args)                       # does not return
     # Libraries (RCCL's version banner, for one) write to stdout; the contract is ONE
     # JSON line there, so everything else is sent to stderr until the line is printed.
     sys.stdout.flush()
@@ -117,16 +252,20 @@ def main():
     import torch.distributed as dist
     from raft_amd import synth
     from raft_amd.device import DeviceBatch, DeviceEngine
-    from raft_amd.sharded import SummaryExchange
+    from raft_amd.sharded import SummaryConsumer, SummaryExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback")
-    dev_index = local_rank % torch.cuda.device_count()    # one rank per GPU on a real node
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit("--gpus %d over RCCL needs %d GPUs, this node shows %d "
+                         "(--backend gloo rehearses several ranks on one GPU)" % (world, world, ndev))
+    dev_index = local_rank % ndev                # one rank per GPU on a real node
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_exchange
@@ -156,10 +295,11 @@ def main():
     depth = S // R
     ex = SummaryExchange(G, device, depth=depth, mode=args.summary, impl=args.exchange_impl,
                          rounds=R) if exchange else None
+    consumer = SummaryConsumer(ex) if (ex is not None and args.consume) else None
 
     # one run-long counter of groups whose commit offset left the 16-bit summary window
     escape_counter = torch.zeros(2, dtype=torch.int32, device=device) if ex is not None else None
-    sets, first_mixed = [], None
+    sets, first_mixed, host_batches = [], None, []
     for s in range(S):
         seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
         if args.workload == "fused":
@@ -175,9 +315,13 @@ def main():
             # indices can only leave the int32 range together with a window base
             b, _ = synth.widen(b, index_shift=(1 << 40) if args.log_window >= 0 else 0,
                                term_shift=1 << 41, id_shift=1 << 42, seed=seed)
+        elif args.workload == "fused":
+            host_batches.append(b)
         kw = {}
         if args.workload == "mixed" and sets:
             kw["share_log_with"] = sets[0]
+        if args.layout == "i32" and args.workload == "fused":
+            kw["log_term_bits"] = args.log_term_bits
         if ex is not None and args.summary == "i32":
             kw.update(commit_out=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R))
         elif ex is not None:
@@ -185,6 +329,7 @@ def main():
                       summary_escapes=escape_counter, summary_bits=ex.bits,
                       summary_base="commit" if ex.bits < 16 else None)
         sets.append(DeviceBatch(b, device, **kw))
+    log_term_bits = sets[0].log_term_bits
     if args.workload == "fused":
         bytes_per_group = alg_bytes_per_group(n, args.what, args.layout)
         workload = "%d groups x %d peers per GPU, fused RequestVote tally + commitIndex advance with log-term gather" % (G, n)
@@ -207,6 +352,8 @@ def main():
             eng.vote_tally(sets[s], variant=args.variant)
         if ex is not None and s % R == R - 1:
             ex.exchange(s // R, async_op=True)   # R rounds of summaries in one collective
+            if consumer is not None:
+                consumer.consume(s // R)         # device-side decode, ordered after the all-gather
 
     def fence():
         if ex is not None:
@@ -216,6 +363,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # untimed: build every set's prepared launch and touch every buffer once
+    for i in range(S):
+        step(i)
+    fence()
     for i in range(args.warmup):
         step(i)
     fence()
@@ -228,6 +379,8 @@ def main():
     ev1.record()                              # same stream as the kernels
     if ex is not None:
         ex.wait_all()
+    while not ev1.query():                    # poll: a blocking wait adds tens of microseconds of wake-up
+        pass                                  # latency, a tenth of a 20-step timed region
     torch.cuda.synchronize(device)
     t1 = time.perf_counter()
     if use_dist:
@@ -236,10 +389,14 @@ def main():
     wall = t1 - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps   # avg launch duration on the kernel's stream
 
+    devices = [dev_index]
     if use_dist:
         tt = torch.tensor([wall], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         wall = float(tt.item())
+        ids = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([dev_index], dtype=torch.int64, device=device))
+        devices = [int(t.item()) for t in ids]
 
     summary_escapes = None
     if ex is not None:      # the 16-bit window must have held on this rank for the whole run
@@ -248,11 +405,18 @@ def main():
         total_groups = G * world
         value = total_groups * args.steps / wall
         achieved = bytes_per_group * G / (kernel_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         try:
             tj = json.load(open(args.traffic_json))
             key = "%s%s_G%d_n%d" % (args.workload, "_i64" if args.layout == "i64" else "", G, n)
-            traffic = tj.get(key, {}).get("hbm_bytes_per_launch")
+            ent = tj.get(key)
+            if ent is not None:
+                if ent.get("kernel_source_hash") == kernel_source_hash():
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    traffic_source = "rocprofv3 --pmc profile %s of kernel %s (not measured by this run)" % (
+                        ent.get("source"), ent.get("kernel"))
+                else:
+                    traffic_source = "none: the kernel source changed since profile %s was taken" % ent.get("source")
         except (OSError, ValueError):
             pass
         line = {
@@ -262,20 +426,31 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int64" if args.layout == "i64" else "int32", "data": "synthetic",
             "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
+                       "preheat_rounds": S,
                        "resident_mb_per_gpu": round(resident_mb, 1),
+                       "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                       "backend": args.backend if use_dist else None, "devices": devices,
                        "summary_allgather": bool(exchange),
                        "summary_bytes_per_rank": ex.nbytes if ex is not None else 0,
                        "summary_mode": args.summary if ex is not None else None,
                        "summary_impl": ex.impl if ex is not None else None,
+                       "summary_consumed_on_device": consumer is not None,
                        "rounds_per_allgather": R if ex is not None else None,
-                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what, "ld_pad": args.ld_pad, "log_window": args.log_window, "layout": args.layout,
+                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what,
+                       "ld_pad": args.ld_pad, "log_window": args.log_window, "layout": args.layout,
+                       "log_term_bits": log_term_bits,
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kernel_ms,
                          "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else "rq_round_joint<16,...>"},
             "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
         }
+        plain = world == 1 and args.workload == "fused" and args.layout == "i32" and args.what == "fused"
+        if plain and not args.no_extras:
+            del sets
+            torch.cuda.empty_cache()
+            line["extra"] = extras(args, torch, synth, DeviceBatch, eng, device, host_batches)
         if world == 1 and not args.no_cpu_baseline and args.workload == "fused":
             line["cpu_baseline"] = cpu_baseline(args, synth)
         sys.stdout.flush()

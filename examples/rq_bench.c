@@ -4,7 +4,7 @@
  * through an rq_plan on the default stream, time from the host clock around
  * `steps` launches and one rq_stream_sync.
  *
- *   rq_bench [groups=1048576] [peers=5] [sets=12] [steps=400] [warmup=40]
+  *   rq_bench [groups=1048576] [peers=5] [sets=12] [steps=400] [warmup=40] [term_bits=8]
  *
  * The batch is drawn here with splitmix64 in the shape of the headline
  * configuration (log lengths U[1,16], matchIndex U[0,len), about half of the
@@ -62,8 +62,9 @@ int main(int argc, char **argv) {
     const uint32_t S = argc > 3 ? (uint32_t)atol(argv[3]) : 12;
     const uint32_t steps = argc > 4 ? (uint32_t)atol(argv[4]) : 400;
     const uint32_t warmup = argc > 5 ? (uint32_t)atol(argv[5]) : 40;
-    if (G < 1 || n < 1 || n > 9 || S < 1 || S > 64 || steps < 1) {
-        fprintf(stderr, "usage: rq_bench [groups] [peers 1..9] [sets 1..64] [steps] [warmup]\n");
+    const uint32_t term_bits = argc > 6 ? (uint32_t)atol(argv[6]) : 8;   /* log-term arena entry width */
+    if (G < 1 || n < 1 || n > 9 || S < 1 || S > 64 || steps < 1 || (term_bits != 8 && term_bits != 16 && term_bits != 32)) {
+        fprintf(stderr, "usage: rq_bench [groups] [peers 1..9] [sets 1..64] [steps] [warmup] [term bits 8|16|32]\n");
         return 2;
     }
     const uint32_t ld = G + 256;                 /* keeps the planes off one power-of-two stride */
@@ -75,8 +76,10 @@ int main(int argc, char **argv) {
     int32_t *commit = calloc(G, 4), *lterm = calloc(G, 4), *cterm = calloc(G, 4), *cid = calloc(G, 4);
     uint32_t *off = calloc((size_t)G + 1, 4);
     int32_t *arena = calloc((size_t)G * 16 + 1, 4);
+    uint8_t *narrow8 = calloc((size_t)G * 16 + 1, 1);
+    uint16_t *narrow16 = calloc((size_t)G * 16 + 1, 2);
     struct set *sets = calloc(S, sizeof *sets);
-    if (!match || !vt || !vf || !ll || !commit || !lterm || !cterm || !cid || !off || !arena || !sets) return 3;
+    if (!match || !vt || !vf || !ll || !commit || !lterm || !cterm || !cid || !off || !arena || !sets || !narrow8 || !narrow16) return 3;
 
     for (uint32_t s = 0; s < S; s++) {
         sm_state = 0x5EED0001ull + 7919ull * s;
@@ -109,7 +112,15 @@ int main(int argc, char **argv) {
         CHECK(upload(e, commit, (size_t)G * 4, &d->commit));
         CHECK(upload(e, lterm, (size_t)G * 4, &d->leader_term));
         CHECK(upload(e, off, ((size_t)G + 1) * 4, &d->log_off));
-        CHECK(upload(e, arena, (total + 1) * 4, &d->log_term));
+        /* the arena as a host keeping it resident stores it: terms here are 1..9, one byte each is enough */
+        if (term_bits == 32) {
+            CHECK(upload(e, arena, (total + 1) * 4, &d->log_term));
+        } else {
+            for (size_t i = 0; i < total; i++) {
+                if (term_bits == 8) narrow8[i] = (uint8_t)arena[i]; else narrow16[i] = (uint16_t)arena[i];
+            }
+            CHECK(upload(e, term_bits == 8 ? (void *)narrow8 : (void *)narrow16, (total + 1) * (term_bits / 8), &d->log_term));
+        }
         CHECK(upload(e, vt, plane * 4, &d->voter_term));
         CHECK(upload(e, vf, plane * 4, &d->voted_for));
         CHECK(upload(e, ll, plane * 4, &d->last_log_term));
@@ -122,12 +133,24 @@ int main(int argc, char **argv) {
         CHECK(rq_device_alloc(e, G, RQ_MEM_DEFAULT, &d->elected));
         CHECK(rq_device_alloc(e, (size_t)G * 4, RQ_MEM_DEFAULT, &d->max_term));
         CHECK(rq_device_alloc(e, G, RQ_MEM_DEFAULT, &d->status));
-        CHECK(rq_plan_fused_round(e, 0, 0, G, n, ld, NULL, NULL, d->match, d->commit, d->leader_term,
-                                  d->log_off, d->log_term, d->voter_term, d->voted_for, d->last_log_term,
-                                  d->cand_term, d->cand_id, d->commit_out, d->voter_term_out, d->grant,
-                                  d->stepdown, d->elected, d->max_term, d->status, NULL, NULL, NULL, NULL,
-                                  NULL, &d->plan));
+        rq_round_desc r;
+        memset(&r, 0, sizeof r);
+        r.struct_size = sizeof r;
+        r.layout = RQ_LAYOUT_I32;
+        r.what = RQ_ROUND_COMMIT | RQ_ROUND_VOTE;
+        r.G = G; r.n = n; r.ld = ld;
+        r.log_terms = total; r.log_term_bits = term_bits;
+        r.match = d->match; r.commit = d->commit; r.leader_term = d->leader_term;
+        r.log_off = d->log_off; r.log_term = d->log_term;
+        r.voter_term = d->voter_term; r.voted_for = d->voted_for; r.voter_last_log_term = d->last_log_term;
+        r.cand_term = d->cand_term; r.cand_id = d->cand_id;
+        r.commit_out = d->commit_out; r.voter_term_out = d->voter_term_out;
+        r.grant_mask = d->grant; r.stepdown_mask = d->stepdown; r.elected = d->elected;
+        r.max_term = d->max_term; r.status_out = d->status;
+        CHECK(rq_plan_round(e, &r, &d->plan));
     }
+    /* one untimed rotation over every set, then the warm-up */
+    for (uint32_t i = 0; i < S; i++) CHECK(rq_plan_launch(sets[i].plan, NULL));
     for (uint32_t i = 0; i < warmup; i++) CHECK(rq_plan_launch(sets[i % S].plan, NULL));
     CHECK(rq_stream_sync(e, NULL));
     struct timespec t0, t1;

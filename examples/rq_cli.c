@@ -6,7 +6,7 @@
  * the library stands on its own outside a torch process.
  *
  *   rq_cli host      rq_fused_round on host buffers
- *   rq_cli device    rq_device_alloc + rq_copy_to_device + rq_fused_round_dev on
+ *   rq_cli device    rq_device_alloc + rq_copy_to_device + rq_round_dev on
  *                    the default stream + rq_stream_sync + rq_copy_from_device
  *
  * Input (whitespace separated integers):
@@ -102,12 +102,21 @@ int main(int argc, char **argv) {
         CHECK(to_device(e, max_term, (size_t)G * 4, &d_mx));
         CHECK(to_device(e, status, G, &d_st));
         /* stream NULL = the device's default stream; variant 0 = library default build */
-        CHECK(rq_fused_round_dev(e, NULL, 0, G, n, G, (const int32_t *)d_match, (const int32_t *)d_commit,
-                                 (const int32_t *)d_lt, (const uint32_t *)d_off, (const int32_t *)d_log,
-                                 (const int32_t *)d_vt, (const int32_t *)d_vf, (const int32_t *)d_ll,
-                                 (const int32_t *)d_ct, (const int32_t *)d_ci, (int32_t *)d_co,
-                                 (int32_t *)d_vto, (uint16_t *)d_gm, (uint16_t *)d_sm, (uint8_t *)d_el,
-                                 (int32_t *)d_mx, (uint8_t *)d_st, NULL, NULL, NULL, NULL, NULL));
+        rq_round_desc d;
+        memset(&d, 0, sizeof d);
+        d.struct_size = sizeof d;
+        d.layout = RQ_LAYOUT_I32;
+        d.what = RQ_ROUND_COMMIT | RQ_ROUND_VOTE;
+        d.G = G; d.n = n; d.ld = G;
+        d.log_terms = arena;
+        d.match = d_match; d.commit = d_commit; d.leader_term = d_lt;
+        d.log_off = (const uint32_t *)d_off; d.log_term = d_log;
+        d.voter_term = d_vt; d.voted_for = d_vf; d.voter_last_log_term = d_ll;
+        d.cand_term = d_ct; d.cand_id = d_ci;
+        d.commit_out = d_co; d.voter_term_out = d_vto;
+        d.grant_mask = (uint16_t *)d_gm; d.stepdown_mask = (uint16_t *)d_sm; d.elected = (uint8_t *)d_el;
+        d.max_term = d_mx; d.status_out = (uint8_t *)d_st;
+        CHECK(rq_round_dev(e, NULL, &d));
         CHECK(rq_stream_sync(e, NULL));
         CHECK(rq_copy_from_device(e, commit_out, d_co, (size_t)G * 4));
         CHECK(rq_copy_from_device(e, voter_term_out, d_vto, plane * 4));

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RQ_VERSION 0x000100 /* 0.1.0 */
+#define RQ_VERSION 0x000200 /* 0.2.0 */
 
 /* return codes */
 #define RQ_OK            0
@@ -57,6 +57,9 @@ extern "C" {
 #define RQ_ST_EMPTY_LOG 0x02u /* vote: a voter reached lastEntry(log)
                                  (raft.go:204, :235) with an empty log; the
                                  reference panics; that voter does not grant  */
+#define RQ_ST_BAD_CSR   0x04u /* device launches: the group's log offsets are
+                                 out of order or point past the arena; nothing
+                                 was read through them, no advance / success   */
 
 /* voter_last_log_term value meaning "this voter's log is empty" */
 #define RQ_LOG_EMPTY INT32_MIN
@@ -75,8 +78,6 @@ int rq_engine_create(int device, uint32_t max_groups, uint32_t max_slots,
                      uint64_t max_log_terms, rq_engine **out);
 int rq_engine_destroy(rq_engine *e);
 int rq_last_hip_error(const rq_engine *e);      /* last hipError_t seen       */
-int rq_engine_set_summary_width(rq_engine *e, int bits); /* 16 (default), 8 or 4; see
-                                                   the device-pointer section  */
 int rq_engine_device(const rq_engine *e);
 
 /* ---- synchronous entry points on caller (host) buffers ------------------ */
@@ -223,153 +224,144 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
 
 /* ---- asynchronous launches on caller-owned DEVICE buffers --------------- *
  * For hosts that keep group state resident in HBM (and for benchmarking
- * without PCIe in the loop).  Every pointer is a device pointer on the
- * engine's device; `stream` is a hipStream_t used as given (NULL = the device's
- * default stream, which is also what torch calls its default stream).
- * The launch is enqueued and the call returns without synchronising.
- * elected_bits, if not NULL, receives the elected decisions packed 1 bit per
- * group ([ceil(G/64)] uint64, bit g%64 of word g/64): the summary vector
- * ranks exchange in a sharded deployment.  commit_lo16, if not NULL, receives
- * the other half of that summary in 16 bits per group: commit'[g] -
- * summary_base[g] (summary_base NULL = 0) when that lies in [0, 65535), else
- * the escape value 65535, in which case *summary_escapes (if not NULL) is
- * incremented (exact up to 65536, it stops growing soon after: the count tells
- * a host that its window is wrong, the escape values themselves tell the
- * receivers which groups) and the receiver must fetch the full commit vector; the host
- * moves summary_base forward before offsets reach the window's end.
- * rq_engine_set_summary_width narrows the summary further for launches and
- * plans made afterwards on that engine: 8 = one byte per group (escape 255),
- * 4 = sixteen groups per 64-bit word, group g in bits 4*(g%16) of word g/16
- * (escape 15; the buffer is then ceil(G/16) words, 8-byte aligned); the buffer
- * is still passed as commit_lo16.  summary_base may be the round's own input
- * commit plane: the summary is then the round's advance, which a receiver adds
- * to the commitIndex it already holds (xGMI links are point-to-point, so the
- * bytes per group on the wire decide how far the exchange of a 30 us round
- * scales).
- * log_base, if not NULL, makes the log arena a window: slot i of group g's
- * arena slice holds log[log_base[g] + i], so a host may keep only the
- * uncommitted suffix of every log on the device (entries at or below
- * commitIndex can never be looked up: the rule needs N > commitIndex); an N
- * below the base is reported as RQ_ST_LOG_OOB like an N past the end.
- * variant selects a kernel build:
- * 0 = library default; other values are tuning knobs listed in rq_kernels.h
- * and never change results. */
-int rq_fused_round_dev(rq_engine *e, void *stream, int variant,
-                       uint32_t G, uint32_t n, uint32_t ld,
-                       const int32_t *match, const int32_t *commit,
-                       const int32_t *leader_term, const uint32_t *log_off,
-                       const int32_t *log_term,
-                       const int32_t *voter_term, const int32_t *voted_for,
-                       const int32_t *voter_last_log_term,
-                       const int32_t *cand_term, const int32_t *cand_id,
-                       int32_t *commit_out, int32_t *voter_term_out,
-                       uint16_t *grant_mask, uint16_t *stepdown_mask,
-                       uint8_t *elected, int32_t *max_term,
-                       uint8_t *status_out, uint64_t *elected_bits,
-                       uint16_t *commit_lo16, const int32_t *summary_base,
-                       uint32_t *summary_escapes, const int32_t *log_base);
-int rq_commit_advance_dev(rq_engine *e, void *stream, int variant,
-                          uint32_t G, uint32_t n, uint32_t ld,
-                          const int32_t *match, const int32_t *commit,
-                          const int32_t *leader_term, const uint32_t *log_off,
-                          const int32_t *log_term, int32_t *commit_out,
-                          uint8_t *status_out, const int32_t *log_base);
-int rq_vote_tally_dev(rq_engine *e, void *stream, int variant,
-                      uint32_t G, uint32_t n, uint32_t ld,
-                      const int32_t *voter_term, const int32_t *voted_for,
-                      const int32_t *voter_last_log_term,
-                      const int32_t *cand_term, const int32_t *cand_id,
-                      int32_t *voter_term_out, uint16_t *grant_mask,
-                      uint16_t *stepdown_mask, uint8_t *elected,
-                      int32_t *max_term, uint8_t *status_out,
-                      uint64_t *elected_bits);
-int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant,
-                             uint32_t G, uint32_t m, uint32_t ld,
-                             const uint16_t *old_mask, const uint16_t *new_mask,
-                             const int32_t *match, const int32_t *commit,
-                             const int32_t *leader_term, const uint32_t *log_off,
-                             const int32_t *log_term,
-                             const int32_t *voter_term, const int32_t *voted_for,
-                             const int32_t *voter_last_log_term,
-                             const int32_t *cand_term, const int32_t *cand_id,
-                             int32_t *commit_out, int32_t *voter_term_out,
-                             uint16_t *grant_mask, uint16_t *stepdown_mask,
-                             uint8_t *elected, int32_t *max_term,
-                             uint8_t *status_out, uint64_t *elected_bits,
-                             uint16_t *commit_lo16, const int32_t *summary_base,
-                             uint32_t *summary_escapes, const int32_t *log_base);
-/* Prepared launches.  rq_plan_fused_round validates one rq_fused_round_dev
- * argument set once (joint = 0) or one rq_fused_round_joint_dev set (joint = 1,
- * old_mask/new_mask then required, n = number of slot planes) and keeps it;
- * rq_plan_launch enqueues it on `stream` with nothing to re-marshal, which
- * matters when a round is only a few microseconds long (10k groups: 1.7 us on
- * the device).  The plan refers to the caller's device buffers, it does not own
- * them; it may be launched any number of times, also under stream capture. */
-typedef struct rq_plan rq_plan;
-int rq_plan_fused_round(rq_engine *e, int variant, int joint,
-                        uint32_t G, uint32_t n, uint32_t ld,
-                        const uint16_t *old_mask, const uint16_t *new_mask,
-                        const int32_t *match, const int32_t *commit,
-                        const int32_t *leader_term, const uint32_t *log_off,
-                        const int32_t *log_term,
-                        const int32_t *voter_term, const int32_t *voted_for,
-                        const int32_t *voter_last_log_term,
-                        const int32_t *cand_term, const int32_t *cand_id,
-                        int32_t *commit_out, int32_t *voter_term_out,
-                        uint16_t *grant_mask, uint16_t *stepdown_mask,
-                        uint8_t *elected, int32_t *max_term,
-                        uint8_t *status_out, uint64_t *elected_bits,
-                        uint16_t *commit_lo16, const int32_t *summary_base,
-                        uint32_t *summary_escapes, const int32_t *log_base, rq_plan **out);
-/* The same for one rq_round64_dev argument set (any `what`, masks optional). */
-int rq_plan_round64(rq_engine *e, int variant, int what,
-                    uint32_t G, uint32_t m, uint32_t ld,
-                    const uint16_t *old_mask, const uint16_t *new_mask,
-                    const int64_t *match, const int64_t *commit,
-                    const int64_t *leader_term, const uint32_t *log_off,
-                    const int64_t *log_term, const int64_t *log_base,
-                    const int64_t *voter_term, const int64_t *voted_for,
-                    const int64_t *voter_last_log_term,
-                    const int64_t *cand_term, const int64_t *cand_id,
-                    int64_t *commit_out, int64_t *voter_term_out,
-                    uint16_t *grant_mask, uint16_t *stepdown_mask,
-                    uint8_t *elected, int64_t *max_term,
-                    uint8_t *status_out, uint64_t *elected_bits,
-                    uint16_t *commit_lo16, const int64_t *summary_base,
-                    uint32_t *summary_escapes, rq_plan **out);
-int rq_plan_launch(rq_plan *p, void *stream);
-int rq_plan_destroy(rq_plan *p);
-
-int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
-                        const uint16_t *active_mask,
-                        const int32_t *follower_term, const int32_t *leader_term,
-                        const int32_t *prev_log_index, const int32_t *prev_log_term,
-                        const int32_t *n_new,
-                        const uint32_t *flog_off, const int32_t *flog_term,
-                        int32_t *follower_term_out, uint16_t *success_mask,
-                        uint16_t *stepdown_mask, int32_t *match_index_io,
-                        int32_t *next_index_io, uint8_t *status_out);
-int rq_stream_sync(rq_engine *e, void *stream);
-
-/* ---- wide layout: 64-bit terms, indices and ids -------------------------- *
- * The same round over int64_t planes, for hosts whose values do not fit the
- * compact layout (Go's int is 64-bit on amd64, raft.go:35-68).  Same rules,
- * same status bits, same masks and byte outputs; an empty voter log is
- * RQ_LOG_EMPTY64.  `what` selects the decisions: RQ_ROUND_COMMIT, RQ_ROUND_VOTE
- * or both (one launch either way); the pointers of the side that is not
- * selected may be NULL.  m slot planes; old_mask/new_mask are either both NULL
- * (every group has the m slots as its one configuration: the fixed-size round)
- * or both given (the joint-consensus round described above).  log_base may be
- * NULL (see the device-pointer section for its meaning); log_off stays 32-bit
- * (it indexes the arena, it is not a Raft value).
- * rq_round64 works on host buffers like rq_fused_round (its 64-bit staging
- * buffers are allocated by the first call and kept); rq_round64_dev enqueues a
- * launch on device buffers like rq_fused_round_joint_dev, with the same
- * variant word (one group per thread in this layout), elected_bits and narrow
- * commit summary. */
+ * without PCIe in the loop).  One descriptor names a round's device buffers
+ * and options; rq_round_dev enqueues it on `stream` (a hipStream_t used as
+ * given; NULL = the device's default stream, which is also what torch calls its
+ * default stream) and returns without synchronising.  The element type of every
+ * term, index and id plane is int32_t (RQ_LAYOUT_I32, the compact layout) or
+ * int64_t (RQ_LAYOUT_I64, the wide layout: Go's int is 64-bit on amd64,
+ * raft.go:35-68; an empty voter log is then RQ_LOG_EMPTY64).  Same rules, same
+ * status bits, same masks and byte outputs in both.
+ *
+ *   what        RQ_ROUND_COMMIT, RQ_ROUND_VOTE or both (one launch either way);
+ *               pointers of the side that is not selected may be NULL.
+ *   old_mask / new_mask   both NULL: every group has the n slots as its one
+ *               configuration (the fixed-size round); both given: the
+ *               joint-consensus round described above, n = number of planes.
+ *   log_off / log_term / log_terms   the leader-log CSR arena and the number of
+ *               entries in it.  No lookup goes at or beyond log_terms, whatever
+ *               log_off holds: a group whose offsets are out of order or point
+ *               past log_terms gets RQ_ST_BAD_CSR and does not advance.
+ *   log_term_bits   width of one arena entry: 0 = the layout's element; 8 or 16
+ *               = unsigned narrow entries, 32 = int32 entries in the wide
+ *               layout.  A round reads ONE term per group but HBM hands out
+ *               128-byte lines, so a narrow arena cuts the gather's traffic by
+ *               the same factor.  log_term_base ([G], may be NULL = 0) is added
+ *               to group g's entries before the comparison with leader_term
+ *               (the host keeps base[g] <= every resident term of the group
+ *               and picks the narrowest width the differences fit).
+ *   log_base    [G], may be NULL: the arena is a window, slot i of group g's
+ *               slice holds log[log_base[g] + i], so a host may keep only the
+ *               uncommitted suffix of every log on the device (entries at or
+ *               below commitIndex can never be looked up: the rule needs N >
+ *               commitIndex); an N below the base is RQ_ST_LOG_OOB like an N
+ *               past the end.
+ *   elected_bits   may be NULL; else the elected decisions packed 1 bit per
+ *               group ([ceil(G/64)] uint64, bit g%64 of word g/64): the summary
+ *               vector ranks exchange in a sharded deployment.
+ *   commit_summary / summary_bits / summary_base / summary_escapes   may be
+ *               NULL; else the other half of that summary, commit'[g] -
+ *               summary_base[g] (NULL = 0) in summary_bits bits per group:
+ *               16 (uint16 per group; 0 means 16), 8 (one byte per group) or 4
+ *               (sixteen groups per 64-bit word, group g in bits 4*(g%16) of
+ *               word g/16; the buffer is ceil(G/16) words, 8-byte aligned).
+ *               A difference that does not fit below the all-ones value is
+ *               stored as all ones (the escape value) and counted in
+ *               *summary_escapes (exact up to 65536, it stops growing soon
+ *               after: the count tells a host that its window is wrong, the
+ *               escape values tell the receivers which groups); the receiver
+ *               then fetches the full commit vector.  summary_base may be the
+ *               round's own input commit plane: the summary is then the round's
+ *               advance, which a receiver adds to the commitIndex it already
+ *               holds (xGMI links are point-to-point, so the bytes per group on
+ *               the wire decide how far the exchange of a 30 us round scales).
+ *   variant     kernel build: 0 = library default; RQ_VARIANT_PLAIN = default
+ *               cache policy instead of non-temporal streaming; bits 8-11 =
+ *               threads per block / 64 (1..4).  Never changes results.
+ * Output planes may alias the matching input plane (commit_out = commit,
+ * voter_term_out = voter_term: state updated in place between rounds). */
+#define RQ_LAYOUT_I32 4
+#define RQ_LAYOUT_I64 8
 #define RQ_LOG_EMPTY64  INT64_MIN
 #define RQ_ROUND_COMMIT 1
 #define RQ_ROUND_VOTE   2
+#define RQ_VARIANT_PLAIN 0x1
+
+typedef struct rq_round_desc {
+    uint32_t struct_size;       /* sizeof(rq_round_desc) */
+    uint32_t layout;            /* RQ_LAYOUT_I32 or RQ_LAYOUT_I64 */
+    uint32_t what;              /* RQ_ROUND_COMMIT | RQ_ROUND_VOTE */
+    int32_t  variant;
+    uint32_t G, n, ld;
+    uint32_t log_term_bits;
+    uint32_t summary_bits;
+    uint32_t reserved;          /* 0 */
+    uint64_t log_terms;
+    const uint16_t *old_mask, *new_mask;
+    /* commit side */
+    const void *match, *commit, *leader_term;
+    const uint32_t *log_off;
+    const void *log_term, *log_base, *log_term_base;
+    /* vote side */
+    const void *voter_term, *voted_for, *voter_last_log_term, *cand_term, *cand_id;
+    /* outputs */
+    void *commit_out, *voter_term_out;
+    uint16_t *grant_mask, *stepdown_mask;
+    uint8_t *elected;
+    void *max_term;
+    uint8_t *status_out;        /* may be NULL */
+    uint64_t *elected_bits;     /* may be NULL */
+    void *commit_summary;       /* may be NULL */
+    const void *summary_base;
+    uint32_t *summary_escapes;
+} rq_round_desc;
+
+int rq_round_dev(rq_engine *e, void *stream, const rq_round_desc *d);
+
+/* Prepared launches.  rq_plan_round validates one descriptor once and keeps a
+ * copy; rq_plan_launch enqueues it on `stream` with nothing to re-marshal,
+ * which matters when a round is only a few microseconds long (10k groups:
+ * 1.7 us on the device).  The plan refers to the caller's device buffers, it
+ * does not own them; it may be launched any number of times, also under stream
+ * capture. */
+typedef struct rq_plan rq_plan;
+int rq_plan_round(rq_engine *e, const rq_round_desc *d, rq_plan **out);
+int rq_plan_launch(rq_plan *p, void *stream);
+int rq_plan_destroy(rq_plan *p);
+
+/* AppendEntries consistency batch on device buffers: the fields of
+ * rq_append_check, plus
+ *   flog_terms      entries in the follower-log arena (same guarantee as
+ *                   log_terms above: RQ_ST_BAD_CSR instead of a stray read);
+ *   flog_term_bits  width of one arena entry (0, 8, 16, 32 as above);
+ *   flog_term_base  [G] or NULL: added to the entries of all followers of group g;
+ *   flog_base       [n][ld] or NULL: follower s keeps only log[flog_base[s] ...]
+ *                   on the device (the suffix around nextIndex is all a
+ *                   consistency check can ask for). */
+typedef struct rq_append_desc {
+    uint32_t struct_size;       /* sizeof(rq_append_desc) */
+    uint32_t layout;            /* RQ_LAYOUT_I32 or RQ_LAYOUT_I64 */
+    uint32_t G, n, ld;
+    uint32_t flog_term_bits;
+    uint64_t flog_terms;
+    const uint16_t *active_mask;
+    const void *follower_term, *leader_term, *prev_log_index, *prev_log_term, *n_new;
+    const uint32_t *flog_off;
+    const void *flog_term, *flog_base, *flog_term_base;
+    void *follower_term_out;
+    uint16_t *success_mask, *stepdown_mask;
+    void *match_index_io, *next_index_io;
+    uint8_t *status_out;
+} rq_append_desc;
+int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d);
+
+int rq_stream_sync(rq_engine *e, void *stream);
+
+/* ---- wide layout on host buffers ----------------------------------------- *
+ * rq_fused_round / rq_follower_clamp / rq_append_check over int64_t planes
+ * (the 64-bit staging buffers are allocated by the first call and kept).
+ * `what` and the optional masks as in rq_round_desc; log_base may be NULL;
+ * log_off stays 32-bit (it indexes the arena, it is not a Raft value). */
 int rq_round64(rq_engine *e, int what, uint32_t G, uint32_t m, uint32_t ld,
                const uint16_t *old_mask, const uint16_t *new_mask,
                const int64_t *match, const int64_t *commit,
@@ -381,24 +373,6 @@ int rq_round64(rq_engine *e, int what, uint32_t G, uint32_t m, uint32_t ld,
                int64_t *commit_out, int64_t *voter_term_out,
                uint16_t *grant_mask, uint16_t *stepdown_mask,
                uint8_t *elected, int64_t *max_term, uint8_t *status_out);
-int rq_round64_dev(rq_engine *e, void *stream, int variant, int what,
-                   uint32_t G, uint32_t m, uint32_t ld,
-                   const uint16_t *old_mask, const uint16_t *new_mask,
-                   const int64_t *match, const int64_t *commit,
-                   const int64_t *leader_term, const uint32_t *log_off,
-                   const int64_t *log_term, const int64_t *log_base,
-                   const int64_t *voter_term, const int64_t *voted_for,
-                   const int64_t *voter_last_log_term,
-                   const int64_t *cand_term, const int64_t *cand_id,
-                   int64_t *commit_out, int64_t *voter_term_out,
-                   uint16_t *grant_mask, uint16_t *stepdown_mask,
-                   uint8_t *elected, int64_t *max_term,
-                   uint8_t *status_out, uint64_t *elected_bits,
-                   uint16_t *commit_lo16, const int64_t *summary_base,
-                   uint32_t *summary_escapes);
-
-/* Wide forms of rq_follower_clamp, rq_append_check and rq_append_check_dev
- * (same rules; int64 planes, 32-bit log offsets). */
 int rq_follower_clamp64(rq_engine *e, uint64_t count, const int64_t *leader_commit,
                         const int64_t *commit, const int64_t *last_new_index,
                         int64_t *commit_out);
@@ -411,15 +385,6 @@ int rq_append_check64(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
                       int64_t *follower_term_out, uint16_t *success_mask,
                       uint16_t *stepdown_mask, int64_t *match_index_io,
                       int64_t *next_index_io, uint8_t *status_out);
-int rq_append_check64_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
-                          const uint16_t *active_mask,
-                          const int64_t *follower_term, const int64_t *leader_term,
-                          const int64_t *prev_log_index, const int64_t *prev_log_term,
-                          const int64_t *n_new,
-                          const uint32_t *flog_off, const int64_t *flog_term,
-                          int64_t *follower_term_out, uint16_t *success_mask,
-                          uint16_t *stepdown_mask, int64_t *match_index_io,
-                          int64_t *next_index_io, uint8_t *status_out);
 
 /* Device memory for hosts that keep group state resident without another GPU
  * runtime binding (a Go host has none), to be used with the *_dev launches.
@@ -468,6 +433,20 @@ int rq_comm_allgather(rq_comm *c, void *compute_stream, uint32_t slot, const voi
 int rq_comm_wait(rq_comm *c, void *compute_stream, uint32_t slot);
 int rq_comm_sync(rq_comm *c);
 int rq_comm_last_error(const rq_comm *c, int *nccl_result, int *hip_error);
+
+/* Consumer side of the exchange, on the device: every rank keeps a replica of
+ * every rank's commitIndex ([ranks][groups] int32) and adds one gathered round of
+ * advance-coded summaries to it, without a host synchronisation.  gathered:
+ * `ranks` messages of msg_stride bytes (the all-gather's receive buffer), the
+ * commit section of one round at byte section_off inside each message, `bits`
+ * (16, 8 or 4) bits per group as written by rq_round_dev with summary_base =
+ * the round's input commit plane.  Escape values leave the replica entry alone
+ * and are counted in *escapes (may be NULL; same saturating count as
+ * summary_escapes): the host then fetches that round's full vector.  Enqueued
+ * on `stream`; order it after the all-gather with rq_comm_wait. */
+int rq_summary_apply_dev(rq_engine *e, void *stream, const void *gathered, uint64_t msg_stride,
+                         uint64_t section_off, uint32_t ranks, uint32_t groups, uint32_t bits,
+                         int32_t *replica, uint32_t *escapes);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,34 @@ u32 = C.c_uint32
 u64 = C.c_uint64
 cint = C.c_int
 
+
+
+class RoundDesc(C.Structure):
+    """rq_round_desc (include/rq.h); every pointer is a raw device address."""
+    _fields_ = [("struct_size", u32), ("layout", u32), ("what", u32), ("variant", C.c_int32),
+                ("G", u32), ("n", u32), ("ld", u32), ("log_term_bits", u32), ("summary_bits", u32),
+                ("reserved", u32), ("log_terms", u64),
+                ("old_mask", vp), ("new_mask", vp),
+                ("match", vp), ("commit", vp), ("leader_term", vp), ("log_off", vp),
+                ("log_term", vp), ("log_base", vp), ("log_term_base", vp),
+                ("voter_term", vp), ("voted_for", vp), ("voter_last_log_term", vp),
+                ("cand_term", vp), ("cand_id", vp),
+                ("commit_out", vp), ("voter_term_out", vp), ("grant_mask", vp), ("stepdown_mask", vp),
+                ("elected", vp), ("max_term", vp), ("status_out", vp), ("elected_bits", vp),
+                ("commit_summary", vp), ("summary_base", vp), ("summary_escapes", vp)]
+
+
+class AppendDesc(C.Structure):
+    """rq_append_desc (include/rq.h)."""
+    _fields_ = [("struct_size", u32), ("layout", u32), ("G", u32), ("n", u32), ("ld", u32),
+                ("flog_term_bits", u32), ("flog_terms", u64),
+                ("active_mask", vp),
+                ("follower_term", vp), ("leader_term", vp), ("prev_log_index", vp), ("prev_log_term", vp),
+                ("n_new", vp), ("flog_off", vp), ("flog_term", vp), ("flog_base", vp), ("flog_term_base", vp),
+                ("follower_term_out", vp), ("success_mask", vp), ("stepdown_mask", vp),
+                ("match_index_io", vp), ("next_index_io", vp), ("status_out", vp)]
+
+
 _COMMIT_IN = [i32p, i32p, i32p, u32p, i32p]          # match commit leader_term log_off log_term
 _VOTE_IN = [i32p, i32p, i32p, i32p, i32p]            # voter_term voted_for last_log_term cand_term cand_id
 _VOTE_OUT = [i32p, u16p, u16p, u8p, i32p]            # voter_term_out grant stepdown elected max_term
@@ -32,7 +60,6 @@ PROTOTYPES = {
     "rq_engine_destroy": [vp],
     "rq_last_hip_error": [vp],
     "rq_engine_device": [vp],
-    "rq_engine_set_summary_width": [vp, cint],
     "rq_commit_advance": [vp, u32, u32, u32] + _COMMIT_IN + [i32p, u8p],
     "rq_vote_tally": [vp, u32, u32, u32] + _VOTE_IN + _VOTE_OUT + [u8p],
     "rq_fused_round": [vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN + [i32p] + _VOTE_OUT + [u8p],
@@ -42,23 +69,18 @@ PROTOTYPES = {
     "rq_follower_clamp": [vp, u64, i32p, i32p, i32p, i32p],
     "rq_append_check": [vp, u32, u32, u32, u16p, i32p, i32p, i32p, i32p, i32p, u32p, i32p,
                         i32p, u16p, u16p, i32p, i32p, u8p],
-    "rq_append_check_dev": [vp, vp, u32, u32, u32] + [vp] * 14,
+    "rq_append_check_dev": [vp, vp, C.POINTER(AppendDesc)],
     "rq_upload": [vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN,
     "rq_step": [vp, u32],
     "rq_download": [vp, i32p] + _VOTE_OUT + [u8p],
-    # device-pointer launches: raw addresses (void*) so torch data_ptr() ints pass through
-    "rq_fused_round_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 22,
-    "rq_commit_advance_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 8,
-    "rq_vote_tally_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 12,
-    "rq_fused_round_joint_dev": [vp, vp, cint, u32, u32, u32] + [vp] * 24,
-    # wide layout: what, G, m, ld, then 2 masks + 11 inputs + 7 outputs (host) / + 4 summary (device)
+    # device-pointer launches: descriptors of raw addresses so torch data_ptr() ints pass through
+    "rq_round_dev": [vp, vp, C.POINTER(RoundDesc)],
+    "rq_plan_round": [vp, C.POINTER(RoundDesc), C.POINTER(vp)],
+    # wide layout on host buffers: what, G, m, ld, then 2 masks + 11 inputs + 7 outputs
     "rq_round64": [vp, cint, u32, u32, u32] + [vp] * 20,
     "rq_follower_clamp64": [vp, u64, vp, vp, vp, vp],
     "rq_append_check64": [vp, u32, u32, u32] + [vp] * 14,
-    "rq_append_check64_dev": [vp, vp, u32, u32, u32] + [vp] * 14,
-    "rq_round64_dev": [vp, vp, cint, cint, u32, u32, u32] + [vp] * 24,
-    "rq_plan_fused_round": [vp, cint, cint, u32, u32, u32] + [vp] * 24 + [C.POINTER(vp)],
-    "rq_plan_round64": [vp, cint, cint, u32, u32, u32] + [vp] * 24 + [C.POINTER(vp)],
+    "rq_summary_apply_dev": [vp, vp, vp, u64, u64, u32, u32, u32, vp, vp],
     "rq_plan_launch": [vp, vp],
     "rq_plan_destroy": [vp],
     "rq_stream_sync": [vp, vp],

@@ -14,7 +14,8 @@ namespace {
 //   reach    : !(term < cur')                                    (:145-147)
 //   success  : reach && log[prevLogIndex].TermNum == prevLogTerm (:151-153)
 //   prevLogIndex outside the follower's log is an index panic in Go: status
-//   bit, no success.
+//   bit, no success.  Follower logs may be windows (flog_base) of narrow entries
+//   (flog_term_bits, flog_term_base), like the leader arena of the round.
 // Leader bookkeeping for the reply (Raft Fig. 2; the reference only declares
 // nextIndex/matchIndex, raft.go:60-68): success -> match = prev + n_new,
 // next = match + 1; rejected at the log check -> next = max(next - 1, 1);
@@ -30,14 +31,15 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     const size_t ld = a.ld;
     const uint32_t n = a.n;
     const T lt = __builtin_nontemporal_load(a.leader_term + g);
+    const T tbase = a.flog_term_base ? __builtin_nontemporal_load(a.flog_term_base + g) : (T)0;
     uint32_t act = a.active_mask ? (uint32_t)a.active_mask[g] : 0xFFFFu;
     act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
     const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
-    T ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX];
+    T ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX], fb[NMAX];
     uint32_t o0[NMAX], o1[NMAX];
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
-        ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
+        ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = fb[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
         if ((act >> p) & 1u) {
             const size_t s = p * ld + g;
             ft[p] = __builtin_nontemporal_load(a.follower_term + s);
@@ -45,22 +47,28 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
             pt[p] = __builtin_nontemporal_load(a.prev_log_term + s);
             o0[p] = __builtin_nontemporal_load(a.flog_off + s);
             o1[p] = a.flog_off[s + 1];
+            if (a.flog_base) fb[p] = __builtin_nontemporal_load(a.flog_base + s);
             if (a.n_new) nn[p] = __builtin_nontemporal_load(a.n_new + s);
             if (a.match_index_io) mi[p] = __builtin_nontemporal_load(a.match_index_io + s);
             if (a.next_index_io) ni[p] = __builtin_nontemporal_load(a.next_index_io + s);
         }
     }
-    uint32_t reach = 0, inb = 0;
+    uint32_t reach = 0, inb = 0, bad = 0;
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
-        const bool r = ((act >> p) & 1u) && lt >= ft[p];
-        const bool in = (U)pi[p] < (U)(o1[p] - o0[p]);
+        const bool on = (act >> p) & 1u;
+        const bool r = on && lt >= ft[p];
+        const bool csr = slice_ok(o0[p], o1[p], a.flog_terms);
+        const U wi = window_slot(pi[p], fb[p]);
+        const bool in = csr && wi < (U)(o1[p] - o0[p]);
         reach |= (uint32_t)r << p;
         inb |= (uint32_t)in << p;
+        bad |= (uint32_t)(on && !csr) << p;
         tg[p] = 0;
-        if (r && in) tg[p] = __builtin_nontemporal_load(a.flog_term + ((size_t)o0[p] + (size_t)(U)pi[p]));
+        if (r && in)
+            tg[p] = (T)((U)load_term<true, T>(a.flog_term, a.flog_term_bits, (size_t)o0[p] + (size_t)wi) + (U)tbase);
     }
-    uint32_t ok = 0, sd = 0, st = 0;
+    uint32_t ok = 0, sd = 0, st = bad ? kStBadCsr : 0;
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
         if (!((act >> p) & 1u)) continue;
@@ -113,6 +121,8 @@ template <typename T>
 hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, hipStream_t stream) {
     if (a.G == 0) return hipSuccess;
     if (a.G > 0x7FFFFFFFu || a.ld < a.G || a.n < 1 || a.n > 16) return hipErrorInvalidValue;
+    const uint32_t tb = a.flog_term_bits;
+    if (tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
     const uint32_t block = 128;
     const dim3 grid((a.G + block - 1) / block), blk(block);
     switch (a.n) {

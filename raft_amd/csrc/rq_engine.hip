@@ -11,13 +11,12 @@
 
 struct rq_plan {
     rq_engine *engine;
-    rq_round_args args;
     uint32_t n;
     bool joint;
+    bool wide;          // args64 is the live member, else args
     int variant;
-    // wide plans (rq_plan_round64) use these instead of args
-    bool wide = false;
-    int what = RQ_WHAT_COMMIT | RQ_WHAT_VOTE;
+    int what;
+    rq_round_args args;
     rq_round64_args args64;
 };
 
@@ -28,7 +27,6 @@ struct rq_engine {
     hipStream_t stream = nullptr;
     std::mutex mu;
     std::atomic<int> last_hip{0};
-    std::atomic<uint32_t> summary_bits{16};   // width of the narrow commit summary (device launches)
     char *slab = nullptr;
     char *slab64 = nullptr;   // staging of the 64-bit host-buffer entry points (made on first use)
     // planes [max_slots][ld]
@@ -100,6 +98,17 @@ int d2h(rq_engine *e, void *dst, const void *src, size_t bytes) {
 }
 
 #define RQ_TRY(x) do { int rq_rc_ = (x); if (rq_rc_ != RQ_OK) return rq_rc_; } while (0)
+
+// A host-buffer entry point that fails after it has enqueued copies must not
+// return while a DMA into or out of the caller's buffers can still be in
+// flight: every exit path that was not disarmed drains the engine's stream.
+struct drain_unless_ok {
+    rq_engine *e;
+    bool armed = true;
+    explicit drain_unless_ok(rq_engine *e_) : e(e_) {}
+    ~drain_unless_ok() { if (armed) (void)hipStreamSynchronize(e->stream); }
+    int ok() { armed = false; return RQ_OK; }
+};
 
 // The engine's staging buffers of one element width.  The 32-bit set is part
 // of the slab made at create time; the 64-bit set is allocated by the first
@@ -183,6 +192,7 @@ rq_round_args_t<T> device_args(rq_engine *e, const staging<T> &s, uint32_t G, ui
     a.G = G; a.ld = e->ld; a.m = m;
     a.match = s.match; a.commit = s.commit; a.leader_term = s.leader_term;
     a.log_off = e->log_off; a.log_term = s.log_term;
+    a.log_terms = e->max_log_terms; a.log_term_bits = 8 * sizeof(T);
     a.voter_term = s.voter_term; a.voted_for = s.voted_for;
     a.last_log_term = s.last_log_term; a.cand_term = s.cand_term; a.cand_id = s.cand_id;
     a.old_mask = joint ? e->old_mask : nullptr;
@@ -263,6 +273,7 @@ int run_host_round(rq_engine *e, const host_round_t<T> &h, int what) {
     RQ_HIP(e, hipSetDevice(e->device));
     e->resident = false;
     if (h.G == 0) return RQ_OK;
+    drain_unless_ok guard(e);
     staging<T> s;
     RQ_TRY(get_staging(e, s));
     RQ_TRY(stage_inputs(e, s, h, what));
@@ -271,26 +282,70 @@ int run_host_round(rq_engine *e, const host_round_t<T> &h, int what) {
     RQ_HIP(e, rq_launch_round(a, h.n, h.joint, what, 0, e->stream));
     RQ_TRY(fetch_outputs(e, s, h, what));
     RQ_HIP(e, hipStreamSynchronize(e->stream));
+    return guard.ok();
+}
+
+// ---- descriptors -> typed kernel arguments ---------------------------------
+
+template <typename T>
+int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
+    const uint32_t what = d.what;
+    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (what & ~(uint32_t)(RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return RQ_E_ARG;
+    if (d.n < 1 || d.n > RQ_MAX_SLOTS || d.ld < d.G || d.G > 0x7FFFFFFFu || d.reserved != 0) return RQ_E_ARG;
+    if ((d.old_mask == nullptr) != (d.new_mask == nullptr)) return RQ_E_ARG;
+    if (what & RQ_WHAT_COMMIT) {
+        if (!d.match || !d.commit || !d.leader_term || !d.log_off || !d.commit_out) return RQ_E_ARG;
+        if (!d.log_term && d.log_terms != 0) return RQ_E_ARG;
+        if (d.log_terms > 0xFFFFFFFFull) return RQ_E_ARG;
+        const uint32_t tb = d.log_term_bits;
+        if (tb != 0 && tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return RQ_E_ARG;
+        if (tb > 8 * sizeof(T)) return RQ_E_ARG;
+    }
+    if (what & RQ_WHAT_VOTE) {
+        if (!d.voter_term || !d.voted_for || !d.voter_last_log_term || !d.cand_term || !d.cand_id ||
+            !d.voter_term_out || !d.grant_mask || !d.stepdown_mask || !d.elected || !d.max_term)
+            return RQ_E_ARG;
+    }
+    const uint32_t sb = d.summary_bits ? d.summary_bits : 16;
+    if (d.commit_summary) {
+        if (sb != 16 && sb != 8 && sb != 4) return RQ_E_ARG;
+        const uintptr_t p = reinterpret_cast<uintptr_t>(d.commit_summary);
+        if ((sb == 16 && (p & 1)) || (sb == 4 && (p & 7))) return RQ_E_ARG;
+    }
+    std::memset(&a, 0, sizeof a);
+    a.G = d.G; a.ld = d.ld; a.m = d.n;
+    a.old_mask = d.old_mask; a.new_mask = d.new_mask;
+    a.match = (const T *)d.match; a.commit = (const T *)d.commit; a.leader_term = (const T *)d.leader_term;
+    a.log_off = d.log_off; a.log_term = d.log_term;
+    a.log_base = (const T *)d.log_base; a.log_term_base = (const T *)d.log_term_base;
+    a.log_terms = d.log_terms;
+    a.log_term_bits = d.log_term_bits ? d.log_term_bits : (uint32_t)(8 * sizeof(T));
+    a.voter_term = (const T *)d.voter_term; a.voted_for = (const T *)d.voted_for;
+    a.last_log_term = (const T *)d.voter_last_log_term;
+    a.cand_term = (const T *)d.cand_term; a.cand_id = (const T *)d.cand_id;
+    a.commit_out = (T *)d.commit_out; a.voter_term_out = (T *)d.voter_term_out;
+    a.grant_mask = d.grant_mask; a.stepdown_mask = d.stepdown_mask; a.elected = d.elected;
+    a.max_term = (T *)d.max_term; a.status_out = d.status_out; a.elected_bits = d.elected_bits;
+    a.commit_lo16 = (uint16_t *)d.commit_summary; a.summary_base = (const T *)d.summary_base;
+    a.summary_escapes = d.summary_escapes; a.summary_bits = sb;
     return RQ_OK;
 }
 
-template <typename T>
-int dev_launch(rq_engine *e, void *stream, int variant, uint32_t n, bool joint, int what,
-                      const rq_round_args_t<T> &a) {
-    if (!e) return RQ_E_ARG;
-    if (n < 1 || n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
-    if (what & RQ_WHAT_COMMIT)
-        if (!a.match || !a.commit || !a.leader_term || !a.log_off || !a.log_term || !a.commit_out)
-            return RQ_E_ARG;
-    if (what & RQ_WHAT_VOTE)
-        if (!a.voter_term || !a.voted_for || !a.last_log_term || !a.cand_term || !a.cand_id ||
-            !a.voter_term_out || !a.grant_mask || !a.stepdown_mask || !a.elected || !a.max_term)
-            return RQ_E_ARG;
-    if (joint && (!a.old_mask || !a.new_mask)) return RQ_E_ARG;
+int plan_from_desc(rq_engine *e, const rq_round_desc *d, rq_plan &p) {
+    if (!e || !d || d->struct_size != sizeof(rq_round_desc)) return RQ_E_ARG;
+    p.engine = e; p.n = d->n; p.joint = d->old_mask != nullptr; p.variant = d->variant; p.what = (int)d->what;
+    std::memset(&p.args, 0, sizeof p.args);
+    std::memset(&p.args64, 0, sizeof p.args64);
+    if (d->layout == RQ_LAYOUT_I32) { p.wide = false; return round_args_from_desc(*d, p.args); }
+    if (d->layout == RQ_LAYOUT_I64) { p.wide = true; return round_args_from_desc(*d, p.args64); }
+    return RQ_E_ARG;
+}
+
+int launch_plan(const rq_plan &p, void *stream) {
+    rq_engine *e = p.engine;
     RQ_HIP(e, hipSetDevice(e->device));
-    rq_round_args_t<T> b = a;
-    b.summary_bits = e->summary_bits.load();
-    hipError_t err = rq_launch_round(b, n, joint, what, variant, (hipStream_t)stream);
+    hipError_t err = p.wide ? rq_launch_round(p.args64, p.n, p.joint, p.what, p.variant, (hipStream_t)stream)
+                            : rq_launch_round(p.args, p.n, p.joint, p.what, p.variant, (hipStream_t)stream);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;
@@ -305,6 +360,7 @@ int follower_clamp_host(rq_engine *e, uint64_t count, const T *leader_commit, co
     RQ_HIP(e, hipSetDevice(e->device));
     e->resident = false;
     if (count == 0) return RQ_OK;
+    drain_unless_ok guard(e);
     staging<T> s;
     RQ_TRY(get_staging(e, s));
     const size_t bytes = (size_t)count * sizeof(T);
@@ -314,7 +370,7 @@ int follower_clamp_host(rq_engine *e, uint64_t count, const T *leader_commit, co
     RQ_HIP(e, rq_launch_follower_clamp(count, s.match, s.voter_term, s.voted_for, s.last_log_term, e->stream));
     RQ_TRY(d2h(e, commit_out, s.last_log_term, bytes));
     RQ_HIP(e, hipStreamSynchronize(e->stream));
-    return RQ_OK;
+    return guard.ok();
 }
 
 template <typename T>
@@ -351,6 +407,7 @@ int append_check_host(rq_engine *e, const rq_append_args_t<T> &h) {
         if (hipMalloc((void **)&e->aux, total) != hipSuccess) return RQ_E_NOMEM;
         e->aux_bytes = total;
     }
+    drain_unless_ok guard(e);
     char *p = e->aux;
     auto take = [&p](size_t bytes) { char *r = p; p += bytes; return r; };
     T *d_ft = (T *)take(plane), *d_pi = (T *)take(plane), *d_pt = (T *)take(plane);
@@ -378,6 +435,7 @@ int append_check_host(rq_engine *e, const rq_append_args_t<T> &h) {
     a.active_mask = h.active_mask ? d_act : nullptr;
     a.follower_term = d_ft; a.leader_term = d_lt; a.prev_log_index = d_pi; a.prev_log_term = d_pt;
     a.n_new = h.n_new ? d_nn : nullptr; a.flog_off = d_off; a.flog_term = d_arena;
+    a.flog_terms = arena; a.flog_term_bits = 8 * E;
     a.follower_term_out = d_fo; a.success_mask = d_ok; a.stepdown_mask = d_sd;
     a.match_index_io = h.match_index_io ? d_mi : nullptr;
     a.next_index_io = h.next_index_io ? d_ni : nullptr;
@@ -390,12 +448,25 @@ int append_check_host(rq_engine *e, const rq_append_args_t<T> &h) {
     RQ_TRY(d2h(e, h.next_index_io, d_ni, slots * E));
     RQ_TRY(d2h(e, h.status_out, d_st, G));
     RQ_HIP(e, hipStreamSynchronize(e->stream));
-    return RQ_OK;
+    return guard.ok();
 }
 
 template <typename T>
-int append_check_dev(rq_engine *e, void *stream, const rq_append_args_t<T> &a) {
-    if (!e) return RQ_E_ARG;
+int append_check_dev(rq_engine *e, void *stream, const rq_append_desc &d) {
+    rq_append_args_t<T> a;
+    std::memset(&a, 0, sizeof a);
+    a.G = d.G; a.ld = d.ld; a.n = d.n; a.active_mask = d.active_mask;
+    a.follower_term = (const T *)d.follower_term; a.leader_term = (const T *)d.leader_term;
+    a.prev_log_index = (const T *)d.prev_log_index; a.prev_log_term = (const T *)d.prev_log_term;
+    a.n_new = (const T *)d.n_new; a.flog_off = d.flog_off; a.flog_term = d.flog_term;
+    a.flog_base = (const T *)d.flog_base; a.flog_term_base = (const T *)d.flog_term_base;
+    a.flog_terms = d.flog_terms;
+    a.flog_term_bits = d.flog_term_bits ? d.flog_term_bits : (uint32_t)(8 * sizeof(T));
+    a.follower_term_out = (T *)d.follower_term_out; a.success_mask = d.success_mask;
+    a.stepdown_mask = d.stepdown_mask; a.match_index_io = (T *)d.match_index_io;
+    a.next_index_io = (T *)d.next_index_io; a.status_out = d.status_out;
+    if (a.flog_term_bits > 8 * sizeof(T) || d.flog_terms > 0xFFFFFFFFull) return RQ_E_ARG;
+    if (!a.flog_term && d.flog_terms == 0) a.flog_term = a.flog_off;   // empty arena: never dereferenced
     RQ_TRY(append_args_ok(a));
     RQ_HIP(e, hipSetDevice(e->device));
     hipError_t err = rq_launch_append_check(a, (hipStream_t)stream);
@@ -520,12 +591,6 @@ int rq_engine_destroy(rq_engine *e) {
     }
     delete e;
     return rc;
-}
-
-int rq_engine_set_summary_width(rq_engine *e, int bits) {
-    if (!e || (bits != 16 && bits != 8 && bits != 4)) return RQ_E_ARG;
-    e->summary_bits.store((uint32_t)bits);
-    return RQ_OK;
 }
 
 int rq_last_hip_error(const rq_engine *e) { return e ? e->last_hip.load() : 0; }
@@ -667,32 +732,6 @@ int rq_append_check64(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
                                              status_out));
 }
 
-int rq_append_check_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
-                    const uint16_t *active_mask, const int32_t *follower_term,
-                    const int32_t *leader_term, const int32_t *prev_log_index,
-                    const int32_t *prev_log_term, const int32_t *n_new,
-                    const uint32_t *flog_off, const int32_t *flog_term,
-                    int32_t *follower_term_out, uint16_t *success_mask, uint16_t *stepdown_mask,
-                    int32_t *match_index_io, int32_t *next_index_io, uint8_t *status_out) {
-    return append_check_dev(e, stream, make_append_args(G, n, ld, active_mask, follower_term, leader_term, prev_log_index,
-                                             prev_log_term, n_new, flog_off, flog_term, follower_term_out,
-                                             success_mask, stepdown_mask, match_index_io, next_index_io,
-                                             status_out));
-}
-
-int rq_append_check64_dev(rq_engine *e, void *stream, uint32_t G, uint32_t n, uint32_t ld,
-                    const uint16_t *active_mask, const int64_t *follower_term,
-                    const int64_t *leader_term, const int64_t *prev_log_index,
-                    const int64_t *prev_log_term, const int64_t *n_new,
-                    const uint32_t *flog_off, const int64_t *flog_term,
-                    int64_t *follower_term_out, uint16_t *success_mask, uint16_t *stepdown_mask,
-                    int64_t *match_index_io, int64_t *next_index_io, uint8_t *status_out) {
-    return append_check_dev(e, stream, make_append_args(G, n, ld, active_mask, follower_term, leader_term, prev_log_index,
-                                             prev_log_term, n_new, flog_off, flog_term, follower_term_out,
-                                             success_mask, stepdown_mask, match_index_io, next_index_io,
-                                             status_out));
-}
-
 int rq_upload(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
               const int32_t *match, const int32_t *commit, const int32_t *leader_term,
               const uint32_t *log_off, const int32_t *log_term,
@@ -709,10 +748,11 @@ int rq_upload(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
     std::lock_guard<std::mutex> lk(e->mu);
     RQ_HIP(e, hipSetDevice(e->device));
     e->resident = false;
+    drain_unless_ok guard(e);
     if (G) RQ_TRY(stage_inputs(e, h, RQ_WHAT_COMMIT | RQ_WHAT_VOTE));
     RQ_HIP(e, hipStreamSynchronize(e->stream));
     e->resident = true; e->res_G = G; e->res_n = n;
-    return RQ_OK;
+    return guard.ok();
 }
 
 int rq_step(rq_engine *e, uint32_t rounds) {
@@ -758,6 +798,7 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
     if (!e->resident) return RQ_E_STATE;
     RQ_HIP(e, hipSetDevice(e->device));
     const uint32_t G = e->res_G;
+    drain_unless_ok guard(e);
     RQ_TRY(d2h(e, commit_out, e->commit, (size_t)G * 4));
     if (voter_term_out && G) RQ_TRY(d2h_planes(e, voter_term_out, e->voter_term, G, e->res_n, G));
     RQ_TRY(d2h(e, grant_mask, e->grant, (size_t)G * 2));
@@ -766,93 +807,7 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
     RQ_TRY(d2h(e, max_term, e->max_term, (size_t)G * 4));
     RQ_TRY(d2h(e, status_out, e->status, (size_t)G));
     RQ_HIP(e, hipStreamSynchronize(e->stream));
-    return RQ_OK;
-}
-
-// ---- device-pointer launches ----------------------------------------------
-
-int rq_fused_round_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n, uint32_t ld,
-                       const int32_t *match, const int32_t *commit, const int32_t *leader_term,
-                       const uint32_t *log_off, const int32_t *log_term,
-                       const int32_t *voter_term, const int32_t *voted_for,
-                       const int32_t *voter_last_log_term, const int32_t *cand_term,
-                       const int32_t *cand_id, int32_t *commit_out, int32_t *voter_term_out,
-                       uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
-                       int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
-                       uint16_t *commit_lo16, const int32_t *summary_base,
-                       uint32_t *summary_escapes, const int32_t *log_base) {
-    rq_round_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.m = n;
-    a.match = match; a.commit = commit; a.leader_term = leader_term;
-    a.log_off = log_off; a.log_term = log_term;
-    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
-    a.cand_term = cand_term; a.cand_id = cand_id;
-    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
-    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
-    a.status_out = status_out; a.elected_bits = elected_bits;
-    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
-    a.log_base = log_base;
-    return dev_launch(e, stream, variant, n, false, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
-}
-
-int rq_commit_advance_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n,
-                          uint32_t ld, const int32_t *match, const int32_t *commit,
-                          const int32_t *leader_term, const uint32_t *log_off,
-                          const int32_t *log_term, int32_t *commit_out, uint8_t *status_out,
-                          const int32_t *log_base) {
-    rq_round_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.m = n;
-    a.match = match; a.commit = commit; a.leader_term = leader_term;
-    a.log_off = log_off; a.log_term = log_term;
-    a.commit_out = commit_out; a.status_out = status_out; a.log_base = log_base;
-    return dev_launch(e, stream, variant, n, false, RQ_WHAT_COMMIT, a);
-}
-
-int rq_vote_tally_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t n, uint32_t ld,
-                      const int32_t *voter_term, const int32_t *voted_for,
-                      const int32_t *voter_last_log_term, const int32_t *cand_term,
-                      const int32_t *cand_id, int32_t *voter_term_out, uint16_t *grant_mask,
-                      uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
-                      uint8_t *status_out, uint64_t *elected_bits) {
-    rq_round_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.m = n;
-    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
-    a.cand_term = cand_term; a.cand_id = cand_id;
-    a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
-    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
-    a.status_out = status_out; a.elected_bits = elected_bits;
-    return dev_launch(e, stream, variant, n, false, RQ_WHAT_VOTE, a);
-}
-
-int rq_fused_round_joint_dev(rq_engine *e, void *stream, int variant, uint32_t G, uint32_t m,
-                             uint32_t ld, const uint16_t *old_mask, const uint16_t *new_mask,
-                             const int32_t *match, const int32_t *commit,
-                             const int32_t *leader_term, const uint32_t *log_off,
-                             const int32_t *log_term, const int32_t *voter_term,
-                             const int32_t *voted_for, const int32_t *voter_last_log_term,
-                             const int32_t *cand_term, const int32_t *cand_id,
-                             int32_t *commit_out, int32_t *voter_term_out, uint16_t *grant_mask,
-                             uint16_t *stepdown_mask, uint8_t *elected, int32_t *max_term,
-                             uint8_t *status_out, uint64_t *elected_bits,
-                             uint16_t *commit_lo16, const int32_t *summary_base,
-                             uint32_t *summary_escapes, const int32_t *log_base) {
-    rq_round_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.m = m;
-    a.old_mask = old_mask; a.new_mask = new_mask;
-    a.match = match; a.commit = commit; a.leader_term = leader_term;
-    a.log_off = log_off; a.log_term = log_term;
-    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
-    a.cand_term = cand_term; a.cand_id = cand_id;
-    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
-    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
-    a.status_out = status_out; a.elected_bits = elected_bits;
-    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
-    a.log_base = log_base;
-    return dev_launch(e, stream, variant, m, true, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, a);
+    return guard.ok();
 }
 
 // ---- wide layout ----------------------------------------------------------
@@ -877,77 +832,6 @@ int rq_round64(rq_engine *e, int what, uint32_t G, uint32_t m, uint32_t ld,
     h.stepdown_mask = stepdown_mask; h.elected = elected; h.max_term = max_term;
     h.status_out = status_out;
     return run_host_round(e, h, what);
-}
-
-int rq_round64_dev(rq_engine *e, void *stream, int variant, int what, uint32_t G, uint32_t m,
-                   uint32_t ld, const uint16_t *old_mask, const uint16_t *new_mask,
-                   const int64_t *match, const int64_t *commit, const int64_t *leader_term,
-                   const uint32_t *log_off, const int64_t *log_term, const int64_t *log_base,
-                   const int64_t *voter_term, const int64_t *voted_for,
-                   const int64_t *voter_last_log_term, const int64_t *cand_term,
-                   const int64_t *cand_id, int64_t *commit_out, int64_t *voter_term_out,
-                   uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
-                   int64_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
-                   uint16_t *commit_lo16, const int64_t *summary_base,
-                   uint32_t *summary_escapes) {
-    if ((old_mask == nullptr) != (new_mask == nullptr)) return RQ_E_ARG;
-    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (what & ~(RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return RQ_E_ARG;
-    rq_round64_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.m = m;
-    a.old_mask = old_mask; a.new_mask = new_mask;
-    a.match = match; a.commit = commit; a.leader_term = leader_term;
-    a.log_off = log_off; a.log_term = log_term; a.log_base = log_base;
-    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
-    a.cand_term = cand_term; a.cand_id = cand_id;
-    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
-    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
-    a.status_out = status_out; a.elected_bits = elected_bits;
-    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
-    return dev_launch(e, stream, variant, m, old_mask != nullptr, what, a);
-}
-
-int rq_plan_round64(rq_engine *e, int variant, int what, uint32_t G, uint32_t m,
-                   uint32_t ld, const uint16_t *old_mask, const uint16_t *new_mask,
-                   const int64_t *match, const int64_t *commit, const int64_t *leader_term,
-                   const uint32_t *log_off, const int64_t *log_term, const int64_t *log_base,
-                   const int64_t *voter_term, const int64_t *voted_for,
-                   const int64_t *voter_last_log_term, const int64_t *cand_term,
-                   const int64_t *cand_id, int64_t *commit_out, int64_t *voter_term_out,
-                   uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
-                   int64_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
-                   uint16_t *commit_lo16, const int64_t *summary_base,
-                   uint32_t *summary_escapes, rq_plan **out) {
-    if (!e || !out) return RQ_E_ARG;
-    *out = nullptr;
-    if ((old_mask == nullptr) != (new_mask == nullptr)) return RQ_E_ARG;
-    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (what & ~(RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return RQ_E_ARG;
-    if (m < 1 || m > RQ_MAX_SLOTS || ld < G || G > 0x7FFFFFFFu) return RQ_E_ARG;
-    if ((what & RQ_WHAT_COMMIT) && (!match || !commit || !leader_term || !log_off || !log_term || !commit_out))
-        return RQ_E_ARG;
-    if ((what & RQ_WHAT_VOTE) && (!voter_term || !voted_for || !voter_last_log_term || !cand_term || !cand_id ||
-                                  !voter_term_out || !grant_mask || !stepdown_mask || !elected || !max_term))
-        return RQ_E_ARG;
-    rq_round64_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.m = m;
-    a.old_mask = old_mask; a.new_mask = new_mask;
-    a.match = match; a.commit = commit; a.leader_term = leader_term;
-    a.log_off = log_off; a.log_term = log_term; a.log_base = log_base;
-    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
-    a.cand_term = cand_term; a.cand_id = cand_id;
-    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
-    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
-    a.status_out = status_out; a.elected_bits = elected_bits;
-    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
-    a.summary_bits = e->summary_bits.load();
-    rq_plan *p = new (std::nothrow) rq_plan();
-    if (!p) return RQ_E_NOMEM;
-    p->engine = e; p->n = m; p->joint = old_mask != nullptr; p->variant = variant;
-    p->wide = true; p->what = what; p->args64 = a;
-    std::memset(&p->args, 0, sizeof p->args);
-    *out = p;
-    return RQ_OK;
 }
 
 int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out) {
@@ -1001,54 +885,44 @@ int rq_copy_from_device(rq_engine *e, void *dst, const void *src, uint64_t bytes
     return RQ_OK;
 }
 
-int rq_plan_fused_round(rq_engine *e, int variant, int joint, uint32_t G, uint32_t n, uint32_t ld,
-                        const uint16_t *old_mask, const uint16_t *new_mask,
-                        const int32_t *match, const int32_t *commit, const int32_t *leader_term,
-                        const uint32_t *log_off, const int32_t *log_term,
-                        const int32_t *voter_term, const int32_t *voted_for,
-                        const int32_t *voter_last_log_term, const int32_t *cand_term,
-                        const int32_t *cand_id, int32_t *commit_out, int32_t *voter_term_out,
-                        uint16_t *grant_mask, uint16_t *stepdown_mask, uint8_t *elected,
-                        int32_t *max_term, uint8_t *status_out, uint64_t *elected_bits,
-                        uint16_t *commit_lo16, const int32_t *summary_base,
-                        uint32_t *summary_escapes, const int32_t *log_base, rq_plan **out) {
-    if (!e || !out) return RQ_E_ARG;
+// ---- device-pointer launches ----------------------------------------------
+
+int rq_round_dev(rq_engine *e, void *stream, const rq_round_desc *d) {
+    rq_plan p;
+    RQ_TRY(plan_from_desc(e, d, p));
+    return launch_plan(p, stream);
+}
+
+int rq_plan_round(rq_engine *e, const rq_round_desc *d, rq_plan **out) {
+    if (!out) return RQ_E_ARG;
     *out = nullptr;
-    rq_round_args a;
-    std::memset(&a, 0, sizeof a);
-    a.G = G; a.ld = ld; a.m = n;
-    a.old_mask = joint ? old_mask : nullptr; a.new_mask = joint ? new_mask : nullptr;
-    a.match = match; a.commit = commit; a.leader_term = leader_term;
-    a.log_off = log_off; a.log_term = log_term;
-    a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = voter_last_log_term;
-    a.cand_term = cand_term; a.cand_id = cand_id;
-    a.commit_out = commit_out; a.voter_term_out = voter_term_out; a.grant_mask = grant_mask;
-    a.stepdown_mask = stepdown_mask; a.elected = elected; a.max_term = max_term;
-    a.status_out = status_out; a.elected_bits = elected_bits;
-    a.commit_lo16 = commit_lo16; a.summary_base = summary_base; a.summary_escapes = summary_escapes;
-    a.log_base = log_base;
-    a.summary_bits = e->summary_bits.load();
-    if (n < 1 || n > RQ_MAX_SLOTS || ld < G || G > 0x7FFFFFFFu) return RQ_E_ARG;
-    if (!match || !commit || !leader_term || !log_off || !log_term || !commit_out || !voter_term ||
-        !voted_for || !voter_last_log_term || !cand_term || !cand_id || !voter_term_out ||
-        !grant_mask || !stepdown_mask || !elected || !max_term)
-        return RQ_E_ARG;
-    if (joint && (!old_mask || !new_mask)) return RQ_E_ARG;
-    rq_plan *p = new (std::nothrow) rq_plan();
+    rq_plan tmp;
+    RQ_TRY(plan_from_desc(e, d, tmp));
+    rq_plan *p = new (std::nothrow) rq_plan(tmp);
     if (!p) return RQ_E_NOMEM;
-    p->engine = e; p->args = a; p->n = n; p->joint = joint != 0; p->variant = variant;
-    std::memset(&p->args64, 0, sizeof p->args64);
     *out = p;
     return RQ_OK;
 }
 
 int rq_plan_launch(rq_plan *p, void *stream) {
     if (!p) return RQ_E_ARG;
-    rq_engine *e = p->engine;
+    return launch_plan(*p, stream);
+}
+
+int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d) {
+    if (!e || !d || d->struct_size != sizeof(rq_append_desc)) return RQ_E_ARG;
+    if (d->layout == RQ_LAYOUT_I32) return append_check_dev<int32_t>(e, stream, *d);
+    if (d->layout == RQ_LAYOUT_I64) return append_check_dev<int64_t>(e, stream, *d);
+    return RQ_E_ARG;
+}
+
+int rq_summary_apply_dev(rq_engine *e, void *stream, const void *gathered, uint64_t msg_stride,
+                         uint64_t section_off, uint32_t ranks, uint32_t groups, uint32_t bits,
+                         int32_t *replica, uint32_t *escapes) {
+    if (!e || !gathered || !replica) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = p->wide
-        ? rq_launch_round(p->args64, p->n, p->joint, p->what, p->variant, (hipStream_t)stream)
-        : rq_launch_round(p->args, p->n, p->joint, RQ_WHAT_COMMIT | RQ_WHAT_VOTE, p->variant, (hipStream_t)stream);
+    hipError_t err = rq_launch_summary_apply((const uint8_t *)gathered, msg_stride, section_off, ranks, groups,
+                                             bits, replica, escapes, (hipStream_t)stream);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;

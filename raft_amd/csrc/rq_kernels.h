@@ -18,8 +18,11 @@ struct rq_round_args_t {
     const T *commit;
     const T *leader_term;
     const uint32_t *log_off;
-    const T *log_term;
-    const T *log_base;    // may be null (0): arena slot 0 of group g holds log[log_base[g]]
+    const void *log_term;     // arena of log_term_bits-wide entries
+    const T *log_base;        // may be null (0): arena slot 0 of group g holds log[log_base[g]]
+    const T *log_term_base;   // may be null (0): added to every arena entry of group g
+    uint64_t log_terms;       // entries in the arena: no lookup goes at or beyond it
+    uint32_t log_term_bits;   // 8, 16 (unsigned entries), 32 (signed) or 8 * sizeof(T)
     // vote side (RequestVoteRPC inputs, raft.go:181-210)
     const T *voter_term;
     const T *voted_for;
@@ -51,25 +54,17 @@ typedef rq_round_args_t<int32_t> rq_round_args;
 typedef rq_round_args_t<int64_t> rq_round64_args;
 
 // Kernel build selector ("variant" in the C-ABI).  Never changes results.
-//   0         library default for the kernel family (see RQ_VAR_DEFAULT_*)
-//   bits 0-3  groups per thread V: 1, 2 or 4 (0 = 1)
-//   bit  4    non-temporal loads of the streamed planes
-//   bit  5    non-temporal stores of the outputs
-//   bit  6    non-temporal log-term gather (only with bits 4 and 5)
-//   bit  7    fused round, V = 1: stage the block's log-arena slice through LDS
-//   bits 8-11 threads per block / 64: 1..4 (0 = 256 threads)
+//   0          library default
+//   bit  0     RQ_VAR_PLAIN: default cache policy for every load and store
+//              (the default build streams everything with non-temporal accesses:
+//              every byte is touched once per round, so nothing is worth keeping
+//              in L2 or the Infinity Cache)
+//   bits 8-11  threads per block / 64: 1..4 (0 = the family's default)
 // Measured on MI355X at 1M groups x 5 slots: one group per thread in
 // 128-thread blocks with non-temporal loads and stores is the fastest fused
 // round (many short blocks keep reads, gathers and writes of different blocks
-// overlapped in time; every byte is touched once per round, so nothing is
-// worth keeping in L2 or the Infinity Cache, the gathered log lines included).
-#define RQ_VAR_V_MASK   0x0F
-#define RQ_VAR_NT_LOAD  0x10
-#define RQ_VAR_NT_STORE 0x20
-#define RQ_VAR_NT_GATHER 0x40  // honoured together with both bits above
-#define RQ_VAR_LDS_LOG  0x80
-#define RQ_VAR_DEFAULT_FIXED 0x271
-#define RQ_VAR_DEFAULT_JOINT 0x131
+// overlapped in time).
+#define RQ_VAR_PLAIN 0x1
 
 #define RQ_WHAT_COMMIT 1
 #define RQ_WHAT_VOTE   2
@@ -79,8 +74,7 @@ typedef rq_round_args_t<int64_t> rq_round64_args;
 // of a.m and the masks.  Returns hipErrorInvalidValue for shapes it rejects.
 hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint,
                            int what, int variant, hipStream_t stream);
-// The same round over 64-bit planes.  Builds: one group per thread; variant
-// bits 4-6 and 8-11 are honoured, the others ignored.
+// The same round over 64-bit planes.
 hipError_t rq_launch_round(const rq_round64_args &a, uint32_t n, bool joint,
                            int what, int variant, hipStream_t stream);
 
@@ -97,7 +91,11 @@ struct rq_append_args_t {
     const T *prev_log_term;         // [n][ld]
     const T *n_new;                 // [n][ld], may be null (0)
     const uint32_t *flog_off;       // [n*ld + 1]
-    const T *flog_term;
+    const void *flog_term;          // arena of flog_term_bits-wide entries
+    const T *flog_base;             // [n][ld], may be null (0): arena slot 0 of slot s holds log[flog_base[s]]
+    const T *flog_term_base;        // [G], may be null (0): added to every arena entry of the group's followers
+    uint64_t flog_terms;            // entries in the arena
+    uint32_t flog_term_bits;        // 8, 16, 32 or 8 * sizeof(T)
     T *follower_term_out;           // [n][ld]
     uint16_t *success_mask;         // [G]
     uint16_t *stepdown_mask;        // [G]
@@ -119,3 +117,13 @@ hipError_t rq_launch_follower_clamp(uint64_t count, const int64_t *leader_commit
                                     const int64_t *commit,
                                     const int64_t *last_new_index,
                                     int64_t *commit_out, hipStream_t stream);
+
+// Summary consumer of a sharded deployment: adds the gathered narrow commit
+// summaries (advance coding) of `ranks` ranks to this rank's replica of every
+// rank's commitIndex.  msg: ranks messages of msg_stride bytes, the commit
+// section of `groups` offsets of `bits` (16, 8, 4) bits at byte offset
+// section_off; replica: [ranks][groups] int32.  Escape values leave the replica
+// entry unchanged and are counted in *escapes.
+hipError_t rq_launch_summary_apply(const uint8_t *msg, uint64_t msg_stride, uint64_t section_off,
+                                   uint32_t ranks, uint32_t groups, uint32_t bits,
+                                   int32_t *replica, uint32_t *escapes, hipStream_t stream);

@@ -18,3 +18,43 @@ hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit
                                     int32_t *commit_out, hipStream_t stream) {
     return launch_follower_clamp_impl<int32_t>(count, leader_commit, commit, last_new_index, commit_out, stream);
 }
+
+// ---------------------------------------------------------------------------
+// Summary consumer (sharded deployment): every rank keeps a replica of every
+// rank's commitIndex and adds the gathered per-round advances to it.  One thread
+// per (rank, group); offsets of 16 / 8 / 4 bits, all ones = escape (left alone,
+// counted with one atomic per wave).
+// ---------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void rq_summary_apply_kernel(const uint8_t *msg, uint64_t msg_stride,
+                                                               uint64_t section_off, uint32_t groups,
+                                                               uint32_t bits, int32_t *replica,
+                                                               uint32_t *escapes) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t r = blockIdx.y;
+    uint32_t esc = 0;
+    if (g < groups) {
+        const uint8_t *sec = msg + (uint64_t)r * msg_stride + section_off;
+        uint32_t v;
+        if (bits == 16) v = reinterpret_cast<const uint16_t *>(sec)[g];
+        else if (bits == 8) v = sec[g];
+        else v = (sec[g >> 1] >> (4 * (g & 1))) & 0xFu;   // little-endian words: group g in bits 4*(g%16)
+        const uint32_t escape = (1u << bits) - 1u;
+        if (v == escape) esc = 1;
+        else if (v) replica[(uint64_t)r * groups + g] += (int32_t)v;
+    }
+    if (escapes) count_escapes(esc, escapes);
+}
+}  // namespace
+
+hipError_t rq_launch_summary_apply(const uint8_t *msg, uint64_t msg_stride, uint64_t section_off,
+                                   uint32_t ranks, uint32_t groups, uint32_t bits,
+                                   int32_t *replica, uint32_t *escapes, hipStream_t stream) {
+    if (ranks == 0 || groups == 0) return hipSuccess;
+    if ((bits != 16 && bits != 8 && bits != 4) || ranks > 65535u) return hipErrorInvalidValue;
+    if (bits == 16 && ((section_off | msg_stride) & 1u)) return hipErrorInvalidValue;
+    const dim3 grid((groups + 255u) / 256u, ranks), blk(256);
+    hipLaunchKernelGGL(rq_summary_apply_kernel, grid, blk, 0, stream, msg, msg_stride, section_off, groups, bits,
+                       replica, escapes);
+    return hipGetLastError();
+}

@@ -3,10 +3,11 @@
 // rq_kernels.hip (int32_t) and rq_kernels64.hip (int64_t).  Internal to
 // librq.so; everything here has internal linkage.
 //
-// One thread owns V consecutive groups (V = 1, 2 or 4) so that every plane is
-// read with one sizeof(T)*V-byte load per lane: a wave reads 64*V contiguous
-// elements of each slot plane, and the 2-byte / 1-byte per-group outputs become
-// 4- or 8-byte stores.  All quorum arithmetic stays in registers:
+// One thread owns V consecutive groups, so a wave reads 64*V contiguous elements
+// of each slot plane.  The library is built with V = 1 (measured fastest on
+// MI355X: 8192 short blocks overlap the read, gather and write phases of
+// different blocks; V = 2 / 4 builds were 10-25 % slower); the bodies stay
+// written over V.  All quorum arithmetic stays in registers:
 //   * commit: compile-time sorting network over the n matchIndex values
 //     (v_min/v_max/v_med3), one gathered log-term load, one compare;
 //   * vote: the reference's RequestVoteRPC predicate per slot (raft.go:181-223)
@@ -21,8 +22,9 @@
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kLdsLogCap = 4096;  // log-arena entries staged per block (16 KiB of int32)
+constexpr int kBlock = 256;            // launch bound
+constexpr int kDefaultBlockFixed = 128;   // measured best for the fixed-size round
+constexpr int kDefaultBlockJoint = 64;    // and for the member-mask round
 
 template <typename T> constexpr T kMinOf = std::numeric_limits<T>::min();
 
@@ -230,15 +232,33 @@ __device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32
     }
 }
 
-constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02;
+constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02, kStBadCsr = 0x04;
 
-// The one dependent, data-indexed load of a round: log[N].TermNum.  The cache
-// policy is a compile-time choice: with a run-time flag the compiler merges
-// the two loads and drops the non-temporal hint.
-template <bool NT, typename T>
-__device__ __forceinline__ T gather_term(const T *p) {
+// The one dependent, data-indexed load of a round: log[N].TermNum.  Arena
+// entries are `bits` wide -- 8 or 16 (unsigned), 32 (signed) or the full element
+// -- a wave-uniform choice, so the switch is a scalar branch around loads of
+// different widths.  The cache policy is a compile-time choice.
+template <bool NT, typename P>
+__device__ __forceinline__ P load_one(const P *p) {
     if constexpr (NT) return __builtin_nontemporal_load(p);
     else return *p;
+}
+template <bool NT, typename T>
+__device__ __forceinline__ T load_term(const void *arena, uint32_t bits, size_t idx) {
+    if (bits == 8) return (T)load_one<NT>(static_cast<const uint8_t *>(arena) + idx);
+    if (bits == 16) return (T)load_one<NT>(static_cast<const uint16_t *>(arena) + idx);
+    if constexpr (sizeof(T) == 8) {
+        if (bits == 32) return (T)load_one<NT>(static_cast<const int32_t *>(arena) + idx);
+    }
+    return load_one<NT>(static_cast<const T *>(arena) + idx);
+}
+
+// A group's slice [beg, end) of a CSR arena of `total` entries is usable when the
+// offsets are ordered and stay inside the arena; then beg + i < total for every
+// i < end - beg, so a lookup guarded by it cannot leave the arena whatever the
+// offsets hold.
+__device__ __forceinline__ bool slice_ok(uint32_t beg, uint32_t end, uint64_t total) {
+    return beg <= end && (uint64_t)end <= total;
 }
 
 // Narrow commit summary: commit' as an offset from a per-group base in `bits`
@@ -323,21 +343,19 @@ __device__ __forceinline__ typename std::make_unsigned<T>::type window_slot(T nq
 // ---------------------------------------------------------------------------
 // fixed cluster size n = N for every group
 // ---------------------------------------------------------------------------
-template <int N, int V, int WHAT, int FLAGS, bool FULL, typename T>
+template <int N, int V, int WHAT, bool NT, bool NTG, bool FULL, typename T>
 __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T> &a,
-                                                     uint32_t g0, int valid,
-                                                     const T *lds_log, uint32_t lds_seg0) {
+                                                     uint32_t g0, int valid) {
     typedef typename std::make_unsigned<T>::type U;
-    constexpr bool NTL = (FLAGS & RQ_VAR_NT_LOAD) != 0;
-    constexpr bool NTS = (FLAGS & RQ_VAR_NT_STORE) != 0;
+    constexpr bool NTL = NT, NTS = NT;
     constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
     constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
     const size_t ld = a.ld;
 
-    T mt[N][V], cm[V], lt[V], lb[V];
+    T mt[N][V], cm[V], lt[V], lb[V], tb[V];
     int32_t off[V + 1];
 #pragma unroll
-    for (int k = 0; k < V; k++) lb[k] = 0;
+    for (int k = 0; k < V; k++) { lb[k] = 0; tb[k] = 0; }
     T vt[N][V], vf[N][V], ll[N][V], ct[V], ci[V];
     uint32_t st[V];
 #pragma unroll
@@ -350,6 +368,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
         ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
         ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
         if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
+        if (a.log_term_base) ld_i32<V, NTL, FULL>(a.log_term_base + g0, valid, tb);
         const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
         int32_t o[V];
         ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -381,17 +400,15 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 #pragma unroll
             for (int p = 0; p < N; p++) s[p] = mt[p][k];
             nq[k] = quorum_index<N>(s);
-            const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
+            const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
+            const bool csr = slice_ok(beg, end, a.log_terms);
             const U wi = window_slot(nq[k], lb[k]);
             adv[k] = (k < valid) && nq[k] > cm[k];
-            inb[k] = wi < (U)len;
+            inb[k] = csr && wi < (U)(end - beg);
+            st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
             gt[k] = 0;
-            if (adv[k] && inb[k]) {
-                if ((FLAGS & RQ_VAR_LDS_LOG) && lds_log)   // the block's arena segment is in LDS
-                    gt[k] = lds_log[(uint32_t)off[k] - lds_seg0 + (uint32_t)wi];
-                else
-                    gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + (size_t)wi));
-            }
+            if (adv[k] && inb[k])
+                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
         }
     }
 
@@ -442,35 +459,14 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     return round_fields{el_field, nib_field, esc_field};
 }
 
-template <int N, int V, int WHAT, int FLAGS, typename T>
+template <int N, int V, int WHAT, bool NT, bool NTG, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-    const T *lds_log = nullptr;
-    uint32_t lds_seg0 = 0;
-    if constexpr ((FLAGS & RQ_VAR_LDS_LOG) != 0 && (WHAT & RQ_WHAT_COMMIT) != 0) {
-        // Stage the block's contiguous slice of the log arena (groups are in CSR
-        // order) through LDS with coalesced loads; the per-group log[N] lookup
-        // then reads LDS.  Blocks whose slice exceeds the buffer gather from
-        // global memory as usual.  All conditions here are block-uniform.
-        __shared__ T staged[kLdsLogCap];
-        const uint64_t b0 = (uint64_t)blockIdx.x * blockDim.x * V;
-        if (b0 < a.G) {
-            const uint64_t b1 = min(b0 + (uint64_t)blockDim.x * V, (uint64_t)a.G);
-            const uint32_t s0 = a.log_off[b0], s1 = a.log_off[b1];
-            if (s1 - s0 <= (uint32_t)kLdsLogCap) {
-                for (uint32_t i = threadIdx.x; i < s1 - s0; i += blockDim.x)
-                    staged[i] = __builtin_nontemporal_load(a.log_term + s0 + i);
-                lds_log = staged;
-                lds_seg0 = s0;
-            }
-        }
-        __syncthreads();
-    }
     round_fields f{0, 0, 0};
     if (g0 + V <= a.G)
-        f = round_fixed_body<N, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, lds_log, lds_seg0);
+        f = round_fixed_body<N, V, WHAT, NT, NTG, true>(a, (uint32_t)g0, V);
     else if (g0 < a.G)
-        f = round_fixed_body<N, V, WHAT, FLAGS, false>(a, (uint32_t)g0, (int)(a.G - g0), lds_log, lds_seg0);
+        f = round_fixed_body<N, V, WHAT, NT, NTG, false>(a, (uint32_t)g0, (int)(a.G - g0));
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
         if (a.elected_bits) pack_elected<V>(f.elected, g0, a.G, a.elected_bits);
     }
@@ -527,13 +523,12 @@ __device__ __forceinline__ T masked_quorum(const T (&mt)[MMAX][V], int k, uint32
 // per-group membership: m slot planes, old/new member masks (joint consensus,
 // mixed cluster sizes).  Null masks mean "all m slots, one configuration".
 // ---------------------------------------------------------------------------
-template <int MMAX, int V, int WHAT, int FLAGS, bool FULL, typename T>
+template <int MMAX, int V, int WHAT, bool NT, bool NTG, bool FULL, typename T>
 __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T> &a,
                                                      uint32_t g0, int valid,
                                                      bool in_range) {
     typedef typename std::make_unsigned<T>::type U;
-    constexpr bool NTL = (FLAGS & RQ_VAR_NT_LOAD) != 0;
-    constexpr bool NTS = (FLAGS & RQ_VAR_NT_STORE) != 0;
+    constexpr bool NTL = NT, NTS = NT;
     constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
     constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
     const size_t ld = a.ld;
@@ -649,14 +644,15 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
                 if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
             }
         }
-        T lb[V];
+        T lb[V], tb[V];
 #pragma unroll
-        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; }
+        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; tb[k] = 0; }
         off[V] = 0;
         if (in_range) {
             ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
             ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
             if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
+            if (a.log_term_base) ld_i32<V, NTL, FULL>(a.log_term_base + g0, valid, tb);
             const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
             int32_t o[V];
             ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -682,12 +678,15 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
                 nn = wave_two_cfgs ? masked_quorum<16, MMAX, V>(mt, k, nm[k]) : no;
             }
             nq[k] = tmin(no, nn);
-            const uint32_t len = (uint32_t)off[k + 1] - (uint32_t)off[k];
+            const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
+            const bool csr = slice_ok(beg, end, a.log_terms);
             const U wi = window_slot(nq[k], lb[k]);
             adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
-            inb[k] = wi < (U)len;
+            inb[k] = csr && wi < (U)(end - beg);
+            st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
             gt[k] = 0;
-            if (adv[k] && inb[k]) gt[k] = gather_term<(FLAGS & RQ_VAR_NT_GATHER) != 0>(a.log_term + ((size_t)(uint32_t)off[k] + (size_t)wi));
+            if (adv[k] && inb[k])
+                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
         }
     }
 
@@ -731,16 +730,16 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
     return round_fields{el_field, nib_field, esc_field};
 }
 
-template <int MMAX, int V, int WHAT, int FLAGS, typename T>
+template <int MMAX, int V, int WHAT, bool NT, bool NTG, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     round_fields f;
     // Every lane runs a body: the wave-wide ballots inside need all of them.
     if (g0 + V <= a.G)
-        f = round_joint_body<MMAX, V, WHAT, FLAGS, true>(a, (uint32_t)g0, V, true);
+        f = round_joint_body<MMAX, V, WHAT, NT, NTG, true>(a, (uint32_t)g0, V, true);
     else {
         const bool in_range = g0 < a.G;
-        f = round_joint_body<MMAX, V, WHAT, FLAGS, false>(
+        f = round_joint_body<MMAX, V, WHAT, NT, NTG, false>(
             a, in_range ? (uint32_t)g0 : 0u, in_range ? (int)(a.G - g0) : 0, in_range);
     }
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
@@ -754,133 +753,60 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
 }
 
 // ---------------------------------------------------------------------------
-// dispatch.  The 32-bit layout is built with V = 1, 2, 4 and every cache-policy
-// combination of the fused round (tuning knobs); the 64-bit layout with V = 1
-// and the two policies "plain" and "all non-temporal".
+// dispatch.  Builds per kernel family, element type and decision set: the
+// default (every streamed access non-temporal) and RQ_VAR_PLAIN; the log-term
+// gather of the default build is non-temporal only while the arena is short
+// (a few lines per group: the gathered line is not used again), and plain for
+// long logs, where it was measured 13 % faster.
 // ---------------------------------------------------------------------------
-template <typename T> constexpr bool kWide = sizeof(T) == 8;
+constexpr uint64_t kNtGatherMaxArenaBytesPerGroup = 256;
 
-template <int N, int V, int WHAT, int FLAGS, typename T>
-hipError_t launch_fixed(const rq_round_args_t<T> &a, uint32_t block, hipStream_t s) {
-    const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
-    const uint32_t grid = (uint32_t)((threads + block - 1) / block);
-    hipLaunchKernelGGL((rq_round_fixed<N, V, WHAT, FLAGS, T>), dim3(grid), dim3(block), 0, s, a);
+template <typename K, typename T>
+hipError_t launch_grid(K kernel, const rq_round_args_t<T> &a, uint32_t block, hipStream_t s) {
+    const uint32_t grid = (uint32_t)(((uint64_t)a.G + block - 1) / block);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, a);
     return hipGetLastError();
 }
 
-template <int N, int V, int WHAT, typename T>
-hipError_t launch_fixed_flags(const rq_round_args_t<T> &a, int flags, uint32_t block, hipStream_t s) {
-    constexpr int kNt = RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE;
-    constexpr int kNtAll = kNt | RQ_VAR_NT_GATHER;
-    constexpr bool kCommit = (WHAT & RQ_WHAT_COMMIT) != 0;
-    // Builds: every kernel comes as "default policy" and "all non-temporal"
-    // (the gather bit only where there is a gather); the 32-bit fused round also
-    // has the single-policy builds and the LDS-staged gather as tuning knobs.
-    if constexpr (kWide<T> || WHAT != (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) {
-        if ((flags & kNt) != kNt) return launch_fixed<N, V, WHAT, 0>(a, block, s);
-        if constexpr (kCommit)
-            if (flags & RQ_VAR_NT_GATHER) return launch_fixed<N, V, WHAT, kNtAll>(a, block, s);
-        return launch_fixed<N, V, WHAT, kNt>(a, block, s);
-    } else {
-        if constexpr (V == 1)
-            if (flags & RQ_VAR_LDS_LOG) return launch_fixed<N, V, WHAT, kNt | RQ_VAR_LDS_LOG>(a, block, s);
-        if ((flags & kNtAll) == kNtAll) return launch_fixed<N, V, WHAT, kNtAll>(a, block, s);
-        switch (flags & kNt) {
-        case 0: return launch_fixed<N, V, WHAT, 0>(a, block, s);
-        case RQ_VAR_NT_LOAD: return launch_fixed<N, V, WHAT, RQ_VAR_NT_LOAD>(a, block, s);
-        case RQ_VAR_NT_STORE: return launch_fixed<N, V, WHAT, RQ_VAR_NT_STORE>(a, block, s);
-        default: return launch_fixed<N, V, WHAT, kNt>(a, block, s);
-        }
-    }
-}
-
+// policy: 0 = plain, 1 = non-temporal streams + plain gather, 2 = all non-temporal
 template <int N, int WHAT, typename T>
-hipError_t launch_fixed_v(const rq_round_args_t<T> &a, int v, int flags, uint32_t block, hipStream_t s) {
-    if constexpr (kWide<T>) {
-        return launch_fixed_flags<N, 1, WHAT>(a, flags, block, s);
-    } else {
-        switch (v) {
-        case 1: return launch_fixed_flags<N, 1, WHAT>(a, flags, block, s);
-        case 2: return launch_fixed_flags<N, 2, WHAT>(a, flags, block, s);
-        default: return launch_fixed_flags<N, 4, WHAT>(a, flags, block, s);
-        }
+hipError_t launch_fixed_policy(const rq_round_args_t<T> &a, int policy, uint32_t block, hipStream_t s) {
+    if (policy == 0) return launch_grid(rq_round_fixed<N, 1, WHAT, false, false, T>, a, block, s);
+    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
+        if (policy == 1) return launch_grid(rq_round_fixed<N, 1, WHAT, true, false, T>, a, block, s);
     }
+    return launch_grid(rq_round_fixed<N, 1, WHAT, true, true, T>, a, block, s);
 }
 
 template <int N, typename T>
-hipError_t launch_fixed_what(const rq_round_args_t<T> &a, int what, int v, int flags, uint32_t block,
-                             hipStream_t s) {
+hipError_t launch_fixed_what(const rq_round_args_t<T> &a, int what, int policy, uint32_t block, hipStream_t s) {
     switch (what) {
-    case RQ_WHAT_COMMIT: return launch_fixed_v<N, RQ_WHAT_COMMIT>(a, v, flags, block, s);
-    case RQ_WHAT_VOTE: return launch_fixed_v<N, RQ_WHAT_VOTE>(a, v, flags, block, s);
-    default: return launch_fixed_v<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, block, s);
+    case RQ_WHAT_COMMIT: return launch_fixed_policy<N, RQ_WHAT_COMMIT>(a, policy, block, s);
+    case RQ_WHAT_VOTE: return launch_fixed_policy<N, RQ_WHAT_VOTE>(a, policy, block, s);
+    default: return launch_fixed_policy<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, policy, block, s);
     }
-}
-
-template <int MMAX, int V, int WHAT, int FLAGS, typename T>
-hipError_t launch_joint(const rq_round_args_t<T> &a, uint32_t block, hipStream_t s) {
-    const uint64_t threads = ((uint64_t)a.G + V - 1) / V;
-    const uint32_t grid = (uint32_t)((threads + block - 1) / block);
-    hipLaunchKernelGGL((rq_round_joint<MMAX, V, WHAT, FLAGS, T>), dim3(grid), dim3(block), 0, s, a);
-    return hipGetLastError();
-}
-
-template <int MMAX, int V, int WHAT, typename T>
-hipError_t launch_joint_flags(const rq_round_args_t<T> &a, int flags, uint32_t block, hipStream_t s) {
-    constexpr int kNt = RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE;
-    if ((flags & kNt) == kNt) return launch_joint<MMAX, V, WHAT, kNt>(a, block, s);
-    return launch_joint<MMAX, V, WHAT, 0>(a, block, s);
 }
 
 template <int MMAX, int WHAT, typename T>
-hipError_t launch_joint_v(const rq_round_args_t<T> &a, int v, int flags, uint32_t block, hipStream_t s) {
-    if constexpr (kWide<T>) {
-        return launch_joint_flags<MMAX, 1, WHAT>(a, flags, block, s);
-    } else {
-        switch (v) {
-        case 1: return launch_joint_flags<MMAX, 1, WHAT>(a, flags, block, s);
-        default: return launch_joint_flags<MMAX, 2, WHAT>(a, flags, block, s);
-        }
+hipError_t launch_joint_policy(const rq_round_args_t<T> &a, int policy, uint32_t block, hipStream_t s) {
+    if (policy == 0) return launch_grid(rq_round_joint<MMAX, 1, WHAT, false, false, T>, a, block, s);
+    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
+        if (policy == 1) return launch_grid(rq_round_joint<MMAX, 1, WHAT, true, false, T>, a, block, s);
     }
+    return launch_grid(rq_round_joint<MMAX, 1, WHAT, true, true, T>, a, block, s);
 }
 
 template <int MMAX, typename T>
-hipError_t launch_joint_what(const rq_round_args_t<T> &a, int what, int v, int flags, uint32_t block,
-                             hipStream_t s) {
+hipError_t launch_joint_what(const rq_round_args_t<T> &a, int what, int policy, uint32_t block, hipStream_t s) {
     switch (what) {
-    case RQ_WHAT_COMMIT: return launch_joint_v<MMAX, RQ_WHAT_COMMIT>(a, v, flags, block, s);
-    case RQ_WHAT_VOTE: return launch_joint_v<MMAX, RQ_WHAT_VOTE>(a, v, flags, block, s);
-    default: return launch_joint_v<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, v, flags, block, s);
+    case RQ_WHAT_COMMIT: return launch_joint_policy<MMAX, RQ_WHAT_COMMIT>(a, policy, block, s);
+    case RQ_WHAT_VOTE: return launch_joint_policy<MMAX, RQ_WHAT_VOTE>(a, policy, block, s);
+    default: return launch_joint_policy<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, policy, block, s);
     }
 }
 
 inline bool aligned_to(const void *p, size_t a) {
     return p == nullptr || (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0;
-}
-
-// Largest V in {4,2,1} not above `want` for which every plane row start
-// (base + p*ld) and every per-group array is aligned for a V-wide access.
-template <typename T>
-int pick_v(const rq_round_args_t<T> &a, int want, int what) {
-    constexpr size_t E = sizeof(T);
-    if (kWide<T>) return 1;
-    for (int v = want; v > 1; v >>= 1) {
-        bool ok = (a.ld % v) == 0;
-        if (what & RQ_WHAT_COMMIT)
-            ok = ok && aligned_to(a.commit_lo16, a.summary_bits == 8 ? v : 2 * v) && aligned_to(a.match, E * v) && aligned_to(a.commit, E * v) &&
-                 aligned_to(a.leader_term, E * v) && aligned_to(a.log_off, 4 * v) && aligned_to(a.log_base, E * v) &&
-                 aligned_to(a.commit_out, E * v);
-        if (what & RQ_WHAT_VOTE)
-            ok = ok && aligned_to(a.voter_term, E * v) && aligned_to(a.voted_for, E * v) &&
-                 aligned_to(a.last_log_term, E * v) && aligned_to(a.cand_term, E * v) &&
-                 aligned_to(a.cand_id, E * v) && aligned_to(a.voter_term_out, E * v) &&
-                 aligned_to(a.grant_mask, 2 * v) && aligned_to(a.stepdown_mask, 2 * v) &&
-                 aligned_to(a.elected, v) && aligned_to(a.max_term, E * v);
-        ok = ok && aligned_to(a.status_out, v) && aligned_to(a.old_mask, 2 * v) &&
-             aligned_to(a.new_mask, 2 * v);
-        if (ok) return v;
-    }
-    return 1;
 }
 
 template <typename T>
@@ -892,28 +818,30 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if (args.commit_lo16 && args.summary_bits != 16 && args.summary_bits != 8 && args.summary_bits != 4)
         return hipErrorInvalidValue;
     if (args.commit_lo16 && args.summary_bits == 4 && !aligned_to(args.commit_lo16, 8)) return hipErrorInvalidValue;
-    if (variant == 0) variant = joint || n > 9 ? RQ_VAR_DEFAULT_JOINT : RQ_VAR_DEFAULT_FIXED;
-    const rq_round_args_t<T> &a = args;
-    const int flags = variant & (RQ_VAR_NT_LOAD | RQ_VAR_NT_STORE | RQ_VAR_NT_GATHER | RQ_VAR_LDS_LOG);
-    int want = variant & RQ_VAR_V_MASK;
-    if (want == 0) want = 1;
-    if (want != 1 && want != 2 && want != 4) return hipErrorInvalidValue;
+    const uint32_t tb = args.log_term_bits;
+    if ((what & RQ_WHAT_COMMIT) && tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
+    if (variant & ~(RQ_VAR_PLAIN | 0xF00)) return hipErrorInvalidValue;
     const int bsel = (variant >> 8) & 0xF;
     if (bsel > 4) return hipErrorInvalidValue;
-    const uint32_t block = bsel ? 64u * (uint32_t)bsel : (uint32_t)kBlock;
+    const bool fixed = !joint && n >= 1 && n <= 9;
+    const uint32_t block = bsel ? 64u * (uint32_t)bsel : (uint32_t)(fixed ? kDefaultBlockFixed : kDefaultBlockJoint);
+    int policy = 2;
+    if (variant & RQ_VAR_PLAIN) policy = 0;
+    else if ((what & RQ_WHAT_COMMIT) &&
+             args.log_terms * (tb / 8) > kNtGatherMaxArenaBytesPerGroup * (uint64_t)args.G) policy = 1;
+    const rq_round_args_t<T> &a = args;
 
-    if (!joint && n >= 1 && n <= 9) {
-        const int v = pick_v(a, want, what);
+    if (fixed) {
         switch (n) {
-        case 1: return launch_fixed_what<1>(a, what, v, flags, block, stream);
-        case 2: return launch_fixed_what<2>(a, what, v, flags, block, stream);
-        case 3: return launch_fixed_what<3>(a, what, v, flags, block, stream);
-        case 4: return launch_fixed_what<4>(a, what, v, flags, block, stream);
-        case 5: return launch_fixed_what<5>(a, what, v, flags, block, stream);
-        case 6: return launch_fixed_what<6>(a, what, v, flags, block, stream);
-        case 7: return launch_fixed_what<7>(a, what, v, flags, block, stream);
-        case 8: return launch_fixed_what<8>(a, what, v, flags, block, stream);
-        default: return launch_fixed_what<9>(a, what, v, flags, block, stream);
+        case 1: return launch_fixed_what<1>(a, what, policy, block, stream);
+        case 2: return launch_fixed_what<2>(a, what, policy, block, stream);
+        case 3: return launch_fixed_what<3>(a, what, policy, block, stream);
+        case 4: return launch_fixed_what<4>(a, what, policy, block, stream);
+        case 5: return launch_fixed_what<5>(a, what, policy, block, stream);
+        case 6: return launch_fixed_what<6>(a, what, policy, block, stream);
+        case 7: return launch_fixed_what<7>(a, what, policy, block, stream);
+        case 8: return launch_fixed_what<8>(a, what, policy, block, stream);
+        default: return launch_fixed_what<9>(a, what, policy, block, stream);
         }
     }
     // per-group membership, or a fixed size beyond the register networks
@@ -921,10 +849,8 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if (!joint) { b.m = n; b.old_mask = nullptr; b.new_mask = nullptr; }
     if (b.m < 1 || b.m > 16) return hipErrorInvalidValue;
     if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
-    if (want > 2) want = 2;
-    const int v = pick_v(b, want, what);
-    if (b.m <= 8) return launch_joint_what<8>(b, what, v, flags, block, stream);
-    return launch_joint_what<16>(b, what, v, flags, block, stream);
+    if (b.m <= 8) return launch_joint_what<8>(b, what, policy, block, stream);
+    return launch_joint_what<16>(b, what, policy, block, stream);
 }
 
 }  // namespace

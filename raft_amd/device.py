@@ -1,19 +1,21 @@
 """Device-resident rounds: group state lives in HBM (torch tensors are used
-only as device allocations) and rq_*_dev launches run on a caller stream.
+only as device allocations) and rq_round_dev launches run on a caller stream.
 
 This is the path a deployment keeps hot between rounds and the one bench.py
 times; the host-buffer entry points in engine.py add PCIe copies around the
 same kernels.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
 from . import _lib
-from ._lib import RqError
+from ._lib import RqError, RoundDesc, AppendDesc
 
 VAR_DEFAULT = 0
-VAR_NT_LOAD = 0x10
-VAR_NT_STORE = 0x20
+VAR_PLAIN = 0x1            # default cache policy instead of non-temporal streaming
+LAYOUT_I32, LAYOUT_I64 = 4, 8
 
 
 def _dev(a, device):
@@ -42,6 +44,38 @@ def decode_summary(raw, groups, bits):
     return nib[:groups]
 
 
+def encode_log_terms(log_term, log_off=None, bits=0, per_group_base=False):
+    """The log-term arena in `bits`-wide entries (what a host keeping the arena
+    resident stores): 8 / 16 = unsigned, 32 = int32, 64 = int64; bits = 0 picks the
+    narrowest of 8, 16 and the array's own width that every entry fits.  With
+    per_group_base the entries are differences from the smallest term of their
+    group's slice (needs log_off); returns (arena, bits, base or None).  A round
+    reads one term per group but HBM hands out 128-byte lines, so the gather's
+    traffic shrinks with the entry width."""
+    t = np.ascontiguousarray(log_term)
+    full = 8 * t.dtype.itemsize
+    base = None
+    v = t.astype(np.int64)
+    if per_group_base:
+        off = np.asarray(log_off).astype(np.int64)
+        G = off.size - 1
+        lens = np.diff(off)
+        base = np.zeros(G, np.int64)
+        nz = lens > 0
+        if v.size:
+            base[nz] = np.minimum.reduceat(v[: off[-1]], off[:-1][nz]) if nz.any() else 0
+        v = v.copy()
+        v[: off[-1]] -= np.repeat(base, lens)
+        base = base.astype(t.dtype)
+    lo, hi = (int(v.min()), int(v.max())) if v.size else (0, 0)
+    if bits == 0:
+        bits = 8 if (lo >= 0 and hi < 256) else 16 if (lo >= 0 and hi < 65536) else full
+    dt = {8: np.uint8, 16: np.uint16, 32: np.int32, 64: np.int64}[bits]
+    if v.size and (lo < np.iinfo(dt).min or hi > np.iinfo(dt).max):
+        raise ValueError("log terms do not fit %d-bit arena entries" % bits)
+    return v.astype(dt), bits, base
+
+
 class DeviceBatch:
     """One batch of groups uploaded to a GPU plus its output buffers."""
 
@@ -50,27 +84,44 @@ class DeviceBatch:
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
                  share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None,
-                 summary_bits=16):
+                 summary_bits=16, log_term_bits=None, log_term_base=False):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         share_log_with: another DeviceBatch whose log_off/log_term device arrays
         are reused (the batch must have been generated with the same logs).
         commit_lo16: device buffer for the narrow commit summary in summary_bits
         (16, 8 or 4) bits per group -- the engine must be set to the same width
-        (DeviceEngine.set_summary_width).  summary_base: a device tensor, None
-        (= 0) or the string "commit" for the batch's own input commit plane (the
-        summary is then the round's advance)."""
+        (the width travels in the launch descriptor).  summary_base: a device
+        tensor, None (= 0) or the string "commit" for the batch's own input commit
+        plane (the summary is then the round's advance).
+        log_term_bits: width of the log-term arena entries on the device: None =
+        the layout's own element (int32 / int64), 0 = the narrowest that fits, or
+        8 / 16 / 32; log_term_base=True stores differences from each group's
+        smallest resident term and uploads that base plane (encode_log_terms)."""
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
         G, n, ld = self.G, self.n, self.ld
         self.joint = "old_mask" in batch
-        self.wide = np.asarray(batch["match"]).dtype == np.int64    # int64 planes (rq_round64_dev)
+        self.wide = np.asarray(batch["match"]).dtype == np.int64    # int64 planes (RQ_LAYOUT_I64)
         vdt, tdt = (np.int64, torch.int64) if self.wide else (np.int32, torch.int32)
         host = {}
+        full_bits = 64 if self.wide else 32
+        self.log_term_bits = full_bits
+        self.log_terms = int(np.asarray(batch["log_term"]).size)
+        enc_term = None
+        if share_log_with is not None:
+            self.log_term_bits, self.log_terms = share_log_with.log_term_bits, share_log_with.log_terms
+        elif log_term_bits is not None or log_term_base:
+            enc_term, self.log_term_bits, tbase = encode_log_terms(
+                batch["log_term"], batch["log_off"], 0 if log_term_bits is None else log_term_bits, log_term_base)
+            if tbase is not None:
+                host["log_term_base"] = np.ascontiguousarray(tbase, dtype=vdt)
         for k in self.IN_KEYS:
             if share_log_with is not None and k in ("log_off", "log_term"):
                 continue
             a = batch[k]
+            if k == "log_term" and enc_term is not None:
+                a = enc_term
             if a.dtype == np.uint32:            # torch has no uint32 arithmetic; same bits
                 a = a.view(np.int32)
             if a.size == 0:
@@ -93,6 +144,8 @@ class DeviceBatch:
         if share_log_with is not None:
             self.t["log_off"] = share_log_with.t["log_off"]
             self.t["log_term"] = share_log_with.t["log_term"]
+            if "log_term_base" in share_log_with.t:
+                self.t["log_term_base"] = share_log_with.t["log_term_base"]
         if in_place:
             o["commit_out"] = self.t["commit"]
             o["voter_term_out"] = self.t["voter_term"]
@@ -163,16 +216,6 @@ class DeviceEngine:
         if rc != 0:
             raise RqError(rc, where, self._l.rq_last_hip_error(self._h))
 
-    def set_summary_width(self, bits):
-        """Width of the narrow commit summary written by later launches and plans."""
-        self._check(self._l.rq_engine_set_summary_width(self._h, bits), "rq_engine_set_summary_width")
-        self._width = bits
-
-    def _match_width(self, b):
-        """The engine-wide width must be the batch's when its launch or plan is made."""
-        if b.o["commit_lo16"] is not None and getattr(self, "_width", 16) != b.summary_bits:
-            self.set_summary_width(b.summary_bits)
-
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream
@@ -196,138 +239,98 @@ class DeviceEngine:
         self._check(self._l.rq_copy_from_device(self._h, array.ctypes.data, addr, array.nbytes),
                     "rq_copy_from_device")
 
-    def fused_round(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
-        """Enqueue one fused round for DeviceBatch b on torch's current stream.
-        The argument set is validated once into an rq_plan per (batch, options);
-        every later call is a two-argument rq_plan_launch."""
-        if b.wide:
-            return self.round64(b, 3, variant, want_bits, status)
-        key = (variant, want_bits, status, b.summary_bits)
+    def describe(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """The rq_round_desc of DeviceBatch b (both layouts, fixed and joint)."""
+        t, o = b.t, b.o
+        p = lambda x: None if x is None else x.data_ptr()
+        commit, vote = bool(what & 1), bool(what & 2)
+        d = RoundDesc()
+        d.struct_size = C.sizeof(RoundDesc)
+        d.layout = LAYOUT_I64 if b.wide else LAYOUT_I32
+        d.what, d.variant = what, variant
+        d.G, d.n, d.ld = b.G, b.n, b.ld
+        d.log_term_bits, d.log_terms = b.log_term_bits, b.log_terms
+        d.summary_bits = b.summary_bits
+        d.old_mask, d.new_mask = p(t.get("old_mask")), p(t.get("new_mask"))
+        if commit:
+            d.match, d.commit, d.leader_term = p(t["match"]), p(t["commit"]), p(t["leader_term"])
+            d.log_off, d.log_term = p(t["log_off"]), p(t["log_term"])
+            d.log_base, d.log_term_base = p(t.get("log_base")), p(t.get("log_term_base"))
+            d.commit_out = p(o["commit_out"])
+            d.commit_summary, d.summary_base = p(o["commit_lo16"]), p(b.summary_base)
+            d.summary_escapes = p(o["summary_escapes"])
+        if vote:
+            d.voter_term, d.voted_for, d.voter_last_log_term = p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"])
+            d.cand_term, d.cand_id = p(t["cand_term"]), p(t["cand_id"])
+            d.voter_term_out, d.grant_mask, d.stepdown_mask = p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"])
+            d.elected, d.max_term = p(o["elected"]), p(o["max_term"])
+            d.elected_bits = p(o["elected_bits"]) if want_bits else None
+        d.status_out = p(o["status"]) if status else None
+        return d
+
+    def round(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """Enqueue the commit (what & 1) and/or vote (what & 2) decision for DeviceBatch b
+        on torch's current stream.  The descriptor is validated once into an rq_plan
+        per (batch, options); every later call is a two-argument rq_plan_launch."""
+        key = (what, variant, want_bits, status)
         plan = b._args.get(key)
         if plan is None:
-            import ctypes as C
-            self._match_width(b)
-            t, o = b.t, b.o
-            p = lambda x: None if x is None else x.data_ptr()
+            d = self.describe(b, what, variant, want_bits, status)
             plan = C.c_void_p()
-            rc = self._l.rq_plan_fused_round(
-                self._h, variant, 1 if b.joint else 0, b.G, b.n, b.ld,
-                p(t.get("old_mask")), p(t.get("new_mask")),
-                p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
-                p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
-                p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
-                p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
-                p(o["elected_bits"]) if want_bits else None,
-                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]), p(t.get("log_base")),
-                C.byref(plan))
+            rc = self._l.rq_plan_round(self._h, C.byref(d), C.byref(plan))
             if rc != 0:
-                self._check(rc, "rq_plan_fused_round")
+                self._check(rc, "rq_plan_round")
             b._args[key] = plan
             b._plans.append((self._l, plan))
         rc = self._l.rq_plan_launch(plan, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             self._check(rc, "rq_plan_launch")
 
-    def fused_round_direct(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
-        """The same round through rq_fused_round_dev / rq_fused_round_joint_dev (all
-        arguments marshalled on every call)."""
-        self._match_width(b)
-        t, o = b.t, b.o
-        p = lambda x: None if x is None else x.data_ptr()
-        tail = [p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
-                p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
-                p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
-                p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
-                p(o["elected_bits"]) if want_bits else None,
-                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"]), p(t.get("log_base"))]
-        if b.joint:
-            rc = self._l.rq_fused_round_joint_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
-                                                  p(t["old_mask"]), p(t["new_mask"]), *tail)
-        else:
-            rc = self._l.rq_fused_round_dev(self._h, self._stream(), variant, b.G, b.n, b.ld, *tail)
+    def round_direct(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """The same round through rq_round_dev (descriptor validated on every call)."""
+        d = self.describe(b, what, variant, want_bits, status)
+        rc = self._l.rq_round_dev(self._h, self._stream(), C.byref(d))
         if rc != 0:
-            self._check(rc, "rq_fused_round_dev")
+            self._check(rc, "rq_round_dev")
 
-    def _round64_args(self, b, want_bits, status):
-        t, o = b.t, b.o
-        p = lambda x: None if x is None else x.data_ptr()
-        return [b.G, b.n, b.ld,
-                p(t.get("old_mask")), p(t.get("new_mask")),
-                p(t["match"]), p(t["commit"]), p(t["leader_term"]), p(t["log_off"]), p(t["log_term"]),
-                p(t.get("log_base")),
-                p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]), p(t["cand_term"]), p(t["cand_id"]),
-                p(o["commit_out"]), p(o["voter_term_out"]), p(o["grant_mask"]), p(o["stepdown_mask"]),
-                p(o["elected"]), p(o["max_term"]), p(o["status"]) if status else None,
-                p(o["elected_bits"]) if want_bits else None,
-                p(o["commit_lo16"]), p(b.summary_base), p(o["summary_escapes"])]
-
-    def round64(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
-        """Enqueue the commit (what & 1) and/or vote (what & 2) decision for a wide
-        (int64) DeviceBatch: validated once into an rq_plan (rq_plan_round64), then
-        launched with rq_plan_launch."""
-        assert b.wide
-        key = ("w", what, variant, want_bits, status, b.summary_bits)
-        plan = b._args.get(key)
-        if plan is None:
-            import ctypes as C
-            self._match_width(b)
-            plan = C.c_void_p()
-            rc = self._l.rq_plan_round64(self._h, variant, what, *self._round64_args(b, want_bits, status),
-                                         C.byref(plan))
-            if rc != 0:
-                self._check(rc, "rq_plan_round64")
-            b._args[key] = plan
-            b._plans.append((self._l, plan))
-        rc = self._l.rq_plan_launch(plan, self._stream())
-        if rc != 0:
-            self._check(rc, "rq_plan_launch")
-
-    def round64_direct(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
-        """The same through rq_round64_dev (all arguments marshalled on every call)."""
-        assert b.wide
-        self._match_width(b)
-        rc = self._l.rq_round64_dev(self._h, self._stream(), variant, what,
-                                    *self._round64_args(b, want_bits, status))
-        if rc != 0:
-            self._check(rc, "rq_round64_dev")
+    def fused_round(self, b, variant=VAR_DEFAULT, want_bits=True, status=True):
+        return self.round(b, 3, variant, want_bits, status)
 
     def commit_advance(self, b, variant=VAR_DEFAULT):
-        if b.wide:
-            return self.round64(b, 1, variant)
-        t, o = b.t, b.o
-        p = lambda x: x.data_ptr()
-        rc = self._l.rq_commit_advance_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
-                                           p(t["match"]), p(t["commit"]), p(t["leader_term"]),
-                                           p(t["log_off"]), p(t["log_term"]), p(o["commit_out"]),
-                                           p(o["status"]),
-                                           t["log_base"].data_ptr() if "log_base" in t else None)
-        self._check(rc, "rq_commit_advance_dev")
+        return self.round(b, 1, variant)
 
     def vote_tally(self, b, variant=VAR_DEFAULT, want_bits=True):
-        if b.wide:
-            return self.round64(b, 2, variant, want_bits)
-        t, o = b.t, b.o
-        p = lambda x: x.data_ptr()
-        rc = self._l.rq_vote_tally_dev(self._h, self._stream(), variant, b.G, b.n, b.ld,
-                                       p(t["voter_term"]), p(t["voted_for"]), p(t["last_log_term"]),
-                                       p(t["cand_term"]), p(t["cand_id"]), p(o["voter_term_out"]),
-                                       p(o["grant_mask"]), p(o["stepdown_mask"]), p(o["elected"]),
-                                       p(o["max_term"]), p(o["status"]),
-                                       p(o["elected_bits"]) if want_bits else None)
-        self._check(rc, "rq_vote_tally_dev")
+        return self.round(b, 2, variant, want_bits)
 
-    def append_check(self, t, G, n, ld):
-        """Enqueue the AppendEntries consistency batch on device tensors (rq_append_check_dev,
-        or rq_append_check64_dev when the planes are int64).  t: dict of tensors with the
-        C-ABI names; active_mask, n_new, match_index, next_index and status may be absent.
-        follower_term_out may be the follower_term tensor itself (in-place terms);
-        match_index / next_index are updated in place."""
+    # names kept for the wide-layout tests
+    def round64(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        assert b.wide
+        return self.round(b, what, variant, want_bits, status)
+
+    def append_check(self, t, G, n, ld, flog_term_bits=0, flog_terms=None):
+        """Enqueue the AppendEntries consistency batch on device tensors
+        (rq_append_check_dev; int32 or int64 planes).  t: dict of tensors with the C-ABI
+        names; active_mask, n_new, match_index, next_index, status, flog_base and
+        flog_term_base may be absent.  follower_term_out may be the follower_term tensor
+        itself (in-place terms); match_index / next_index are updated in place.
+        flog_term_bits: entry width of the flog_term tensor (0 = the planes' element)."""
         wide = t["follower_term"].dtype == torch.int64
         p = lambda k: t[k].data_ptr() if t.get(k) is not None else None
-        fn = self._l.rq_append_check64_dev if wide else self._l.rq_append_check_dev
-        rc = fn(self._h, self._stream(), G, n, ld, p("active_mask"), p("follower_term"), p("leader_term"),
-                p("prev_log_index"), p("prev_log_term"), p("n_new"), p("flog_off"), p("flog_term"),
-                p("follower_term_out"), p("success_mask"), p("stepdown_mask"), p("match_index"),
-                p("next_index"), p("status"))
+        d = AppendDesc()
+        d.struct_size = C.sizeof(AppendDesc)
+        d.layout = LAYOUT_I64 if wide else LAYOUT_I32
+        d.G, d.n, d.ld = G, n, ld
+        d.flog_term_bits = flog_term_bits
+        d.flog_terms = t["flog_term"].numel() if flog_terms is None else flog_terms
+        d.active_mask = p("active_mask")
+        d.follower_term, d.leader_term = p("follower_term"), p("leader_term")
+        d.prev_log_index, d.prev_log_term, d.n_new = p("prev_log_index"), p("prev_log_term"), p("n_new")
+        d.flog_off, d.flog_term = p("flog_off"), p("flog_term")
+        d.flog_base, d.flog_term_base = p("flog_base"), p("flog_term_base")
+        d.follower_term_out = p("follower_term_out")
+        d.success_mask, d.stepdown_mask = p("success_mask"), p("stepdown_mask")
+        d.match_index_io, d.next_index_io = p("match_index"), p("next_index")
+        d.status_out = p("status")
+        rc = self._l.rq_append_check_dev(self._h, self._stream(), C.byref(d))
         if rc != 0:
             self._check(rc, "rq_append_check_dev")

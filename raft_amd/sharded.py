@@ -243,9 +243,59 @@ class SummaryExchange:
             if self._full is None:
                 self._full = torch.zeros((self.world, self.groups), dtype=torch.int32, device=self.device)
             if dist.is_initialized():
+                # one communicator at a time: the native communicator's queued all-gathers
+                # are drained before a collective goes out on the process group's own
+                if self._comm is not None:
+                    self.wait_all()
                 dist.all_gather_into_tensor(self._full.view(-1), full_local_commit.contiguous(), group=self.group)
             else:
                 self._full[0].copy_(full_local_commit)
             return self._full
         out = self._offsets(slot, sub)
         return out if base is None else out + base
+
+
+class SummaryConsumer:
+    """Consumer side of the exchange without a host synchronisation: this rank's
+    replica of EVERY rank's commitIndex ([world, groups] int32 on the device) is
+    advanced by each gathered round of advance-coded summaries (narrow modes with
+    the round's input commit plane as the base) in a small kernel on the compute
+    stream, ordered after the slot's all-gather.  Escape values are counted in a
+    device counter (`escapes[0]`) and leave the replica entry alone; a host that
+    finds the counter non-zero fetches the full vectors of that period."""
+
+    def __init__(self, ex, initial=None):
+        assert ex.bits in (16, 8, 4), "the device consumer decodes the narrow (advance-coded) summaries"
+        assert ex.device.type == "cuda", "rq_summary_apply_dev is a GPU kernel"
+        import ctypes as C
+        from . import _lib
+        self.ex = ex
+        self._l = _lib.lib()
+        h = C.c_void_p()
+        rc = self._l.rq_engine_create(ex.device.index or 0, 64, 1, 64, C.byref(h))
+        if rc != 0:
+            raise _lib.RqError(rc, "rq_engine_create")
+        self._h = h
+        self.replica = torch.zeros((ex.world, ex.groups), dtype=torch.int32, device=ex.device)
+        if initial is not None:
+            self.replica.copy_(initial)
+        self.escapes = torch.zeros(2, dtype=torch.int32, device=ex.device)
+
+    def consume(self, slot):
+        """Apply every round of `slot`'s gathered message to the replica.  Call after
+        ex.exchange(slot); the kernels are ordered after that all-gather on the
+        current stream and before the slot's next all-gather."""
+        ex = self.ex
+        ex.wait(slot)
+        stream = torch.cuda.current_stream(ex.device).cuda_stream
+        for sub in range(ex.rounds):
+            rc = self._l.rq_summary_apply_dev(self._h, stream, ex.all[slot].data_ptr(), ex.nbytes,
+                                              sub * ex.round_bytes, ex.world, ex.groups, ex.bits,
+                                              self.replica.data_ptr(), self.escapes.data_ptr())
+            if rc != 0:
+                raise _lib.RqError(rc, "rq_summary_apply_dev", self._l.rq_last_hip_error(self._h))
+
+    def close(self):
+        if self._h:
+            self._l.rq_engine_destroy(self._h)
+            self._h = None

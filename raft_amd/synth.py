@@ -312,6 +312,28 @@ def window_logs(b, keep_committed=0):
     return w
 
 
+def window_flogs(b, keep_before=1):
+    """A copy of AppendEntries batch b whose follower-log arena holds, for every slot,
+    only the entries from prevLogIndex - keep_before on (the suffix around nextIndex:
+    all a consistency check can ask for); adds flog_base [n, ld].  Decisions are
+    unchanged: the check reads log[prevLogIndex] only, and an index outside the log
+    stays outside the window."""
+    n, ld = b["prev_log_index"].shape
+    off = b["flog_off"].astype(np.int64)
+    lens = np.diff(off)
+    pi = b["prev_log_index"].astype(np.int64).ravel()
+    base = np.clip(pi - keep_before, 0, lens)
+    new_lens = lens - base
+    new_off = _csr(new_lens)
+    slot = np.repeat(np.arange(lens.size, dtype=np.int64), new_lens)
+    pos = np.arange(int(new_off[-1]), dtype=np.int64) - new_off[:-1].astype(np.int64)[slot]
+    arena = b["flog_term"][off[:-1][slot] + base[slot] + pos] if slot.size else np.zeros(0, b["flog_term"].dtype)
+    w = Batch(b)
+    w["flog_off"], w["flog_term"] = new_off, np.ascontiguousarray(arena)
+    w["flog_base"] = base.astype(b["prev_log_index"].dtype).reshape(n, ld)
+    return w
+
+
 LOG_EMPTY64 = np.iinfo(np.int64).min
 _WIDE_FIELDS = ("match", "commit", "leader_term", "log_term", "voter_term", "voted_for",
                 "last_log_term", "cand_term", "cand_id", "log_base")

@@ -218,7 +218,20 @@ def _check_dev(res, exp, G, members=None):
     assert not np.unpackbits(res["elected_bits"].view(np.uint8), bitorder="little")[G:].any()
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 0x14, 0x24, 0x34, 0x31, 0x32, 0x231, 0x134, 0x412, 0x2b1, 0x1f1])
+def _raw_round(dev, stream, what, G, n, ld, wide=False, variant=0, **ptrs):
+    """rq_round_dev on raw device addresses: ptrs are rq_round_desc field names."""
+    import ctypes as C
+    from raft_amd._lib import RoundDesc
+    d = RoundDesc()
+    d.struct_size = C.sizeof(RoundDesc)
+    d.layout = 8 if wide else 4
+    d.what, d.variant, d.G, d.n, d.ld = what, variant, G, n, ld
+    for k, v in ptrs.items():
+        setattr(d, k, v)
+    return dev._l.rq_round_dev(dev._h, stream, C.byref(d))
+
+
+@pytest.mark.parametrize("variant", [0, 1, 0x100, 0x201, 0x300, 0x401])
 def test_device_launch_variants(dev, variant):
     from raft_amd.device import DeviceBatch
     for n in (3, 5, 9):
@@ -253,7 +266,7 @@ def test_device_joint_and_split_kernels(dev):
     from raft_amd.device import DeviceBatch
     b = synth.gen_mixed(30000, seed=4)
     exp = o.fused_round(*b.fused_args(), old_mask=b.old_mask, new_mask=b.new_mask)
-    for variant in (0, 1, 2):
+    for variant in (0, 1, 0x200):
         db = DeviceBatch(b)
         dev.fused_round(db, variant=variant)
         _check_dev(db.results(), exp, b.G, member_matrix(b))
@@ -456,15 +469,10 @@ def test_device_resident_replication_rounds(dev, wide):
         dev.append_check(t, G, n, ld)
         # commit over the matchIndex plane the append kernel has just updated
         p = lambda x: x.data_ptr()
-        if wide:
-            rc = dev._l.rq_round64_dev(dev._h, dev._stream(), 0, 1, G, n, ld, None, None, p(d_mi), p(d_commit),
-                                       p(d_lead["leader_term"]), p(d_lead["log_off"]), p(d_lead["log_term"]), None,
-                                       None, None, None, None, None, p(d_commit), None, None, None, None, None,
-                                       p(d_status), None, None, None, None)
-        else:
-            rc = dev._l.rq_commit_advance_dev(dev._h, dev._stream(), 0, G, n, ld, p(d_mi), p(d_commit),
-                                              p(d_lead["leader_term"]), p(d_lead["log_off"]), p(d_lead["log_term"]),
-                                              p(d_commit), p(d_status), None)
+        rc = _raw_round(dev, dev._stream(), 1, G, n, ld, wide=wide, match=p(d_mi), commit=p(d_commit),
+                        leader_term=p(d_lead["leader_term"]), log_off=p(d_lead["log_off"]),
+                        log_term=p(d_lead["log_term"]), log_terms=lead.log_term.size,
+                        commit_out=p(d_commit), status_out=p(d_status))
         assert rc == 0
         # the same on the host
         fn = o.append_check64 if wide else o.append_check
@@ -503,7 +511,9 @@ def test_device_memory_helpers_round_trip(dev):
     back = np.zeros_like(b.match)
     dev.download(addrs[0], back)
     assert np.array_equal(back, b.match)
-    rc = dev._l.rq_commit_advance_dev(dev._h, None, 0, b.G, b.n, b.ld, *addrs, None)
+    rc = _raw_round(dev, None, 1, b.G, b.n, b.ld, match=addrs[0], commit=addrs[1], leader_term=addrs[2],
+                    log_off=addrs[3], log_term=addrs[4], log_terms=b.log_term.size, commit_out=addrs[5],
+                    status_out=addrs[6])
     assert rc == 0
     assert dev._l.rq_stream_sync(dev._h, None) == 0
     c = np.zeros(b.G, np.int32); st = np.zeros(b.G, np.uint8)
@@ -513,7 +523,7 @@ def test_device_memory_helpers_round_trip(dev):
         dev.free(addr)
 
 
-@pytest.mark.parametrize("variant", [0, 0x234, 0x132])
+@pytest.mark.parametrize("variant", [0, 1, 0x300])
 def test_narrow_commit_summary(dev, variant):
     """commit_lo16 = commit' - base inside the 16-bit window, 65535 + an escape
     count outside it; fixed and joint kernels."""
@@ -521,7 +531,7 @@ def test_narrow_commit_summary(dev, variant):
     from raft_amd.device import DeviceBatch
     rng = np.random.default_rng(5)
     for joint in (False, True):
-        G = 70000 if variant != 0x234 else 70016
+        G = 70000
         b = synth.gen_mixed(G, seed=3) if joint else synth.gen_fused(G, 5, seed=3, ld=G)
         # push some groups out of the window on both sides
         far = rng.random(G) < 0.01
@@ -544,9 +554,9 @@ def test_narrow_commit_summary(dev, variant):
 
 
 @pytest.mark.parametrize("bits", [8, 4])
-@pytest.mark.parametrize("variant", [0, 0x234, 0x132, 0x131])
+@pytest.mark.parametrize("variant", [0, 1, 0x300, 0x101])
 def test_commit_summary_widths(dev, variant, bits):
-    """The 8- and 4-bit commit summaries (rq_engine_set_summary_width): offsets from an
+    """The 8- and 4-bit commit summaries (summary_bits of the descriptor): offsets from an
     explicit base and from the round's own input commit plane (the round's advance),
     fixed, joint and wide kernels, group counts that do not fill the last word."""
     import torch
@@ -582,9 +592,14 @@ def test_commit_summary_widths(dev, variant, bits):
             assert res["summary_escapes"] == int((~fit).sum()), (kind, G, base_kind)
             # nothing is written past the summary's last word
             assert bool((buf[summary_buffer_bytes(G, bits):] == 0xAB).all())
-    assert dev._l.rq_engine_set_summary_width(dev._h, 5) == -1        # only 16, 8 and 4 exist
-    assert dev._l.rq_engine_set_summary_width(None, 8) == -1
-    dev.set_summary_width(16)
+    # only 16, 8 and 4 exist; a 4-bit summary buffer must be 8-byte aligned
+    import ctypes as C
+    d = dev.describe(db)
+    d.summary_bits = 5
+    assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == -1
+    d.summary_bits = 4
+    d.commit_summary = buf.data_ptr() + 4
+    assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == -1
 
 
 def test_native_rccl_summary_allgather_one_rank(dev):
@@ -619,14 +634,14 @@ def test_native_rccl_summary_allgather_one_rank(dev):
 
 def test_plan_launch_equals_direct_launch(dev):
     """rq_plan_* (validated once, launched many times) and the per-call
-    rq_fused_round_dev / rq_fused_round_joint_dev path give identical outputs."""
+    rq_round_dev path give identical outputs."""
     from raft_amd.device import DeviceBatch
     for b, kw in ((synth.gen_adversarial(33333, 7, seed=2), {}),
                   (synth.gen_mixed(20000, seed=6), {})):
         a, d = DeviceBatch(b), DeviceBatch(b)
         for _ in range(3):
             dev.fused_round(a)
-        dev.fused_round_direct(d)
+        dev.round_direct(d)
         ra, rd = a.results(), d.results()
         for k in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status", "elected_bits"):
             assert np.array_equal(ra[k], rd[k]), k
@@ -652,13 +667,15 @@ def test_plane_offsets_beyond_4_gib(dev):
                sd=torch.zeros(G, dtype=torch.int16, device=d), el=torch.zeros(G, dtype=torch.uint8, device=d),
                mx=torch.zeros(G, dtype=torch.int32, device=d), st=torch.zeros(G, dtype=torch.uint8, device=d))
     p = lambda t: t.data_ptr()
-    for variant in (0, 0x234):
-        rc = dev._l.rq_fused_round_dev(dev._h, torch.cuda.current_stream().cuda_stream, variant, G, n, ld,
-                                       p(planes["match"]), p(vec["commit"]), p(vec["leader_term"]), p(vec["log_off"]),
-                                       p(vec["log_term"]), p(planes["voter_term"]), p(planes["voted_for"]),
-                                       p(planes["last_log_term"]), p(vec["cand_term"]), p(vec["cand_id"]),
-                                       p(out["commit"]), p(vt_out), p(out["grant"]), p(out["sd"]), p(out["el"]),
-                                       p(out["mx"]), p(out["st"]), None, None, None, None, None)
+    for variant in (0, 1):
+        rc = _raw_round(dev, torch.cuda.current_stream().cuda_stream, 3, G, n, ld, variant=variant,
+                        match=p(planes["match"]), commit=p(vec["commit"]), leader_term=p(vec["leader_term"]),
+                        log_off=p(vec["log_off"]), log_term=p(vec["log_term"]), log_terms=b.log_term.size,
+                        voter_term=p(planes["voter_term"]), voted_for=p(planes["voted_for"]),
+                        voter_last_log_term=p(planes["last_log_term"]), cand_term=p(vec["cand_term"]),
+                        cand_id=p(vec["cand_id"]), commit_out=p(out["commit"]), voter_term_out=p(vt_out),
+                        grant_mask=p(out["grant"]), stepdown_mask=p(out["sd"]), elected=p(out["el"]),
+                        max_term=p(out["mx"]), status_out=p(out["st"]))
         assert rc == 0
         torch.cuda.synchronize()
         assert np.array_equal(out["commit"].cpu().numpy(), exp.commit)
@@ -690,7 +707,7 @@ def test_pinned_host_buffers(engine):
     assert_vote_equal(got, exp, b.G)
 
 
-@pytest.mark.parametrize("variant", [0, 0x234, 0x1b1])
+@pytest.mark.parametrize("variant", [0, 1, 0x300])
 def test_windowed_log_arena(dev, variant):
     """log_base: the arena holds only a suffix of every log.  Same decisions as
     with the full logs whenever the window still covers N; N below the base is a
@@ -728,7 +745,7 @@ def test_fuzz_shapes_and_variants(dev):
     """Random group counts, cluster sizes, plane strides and kernel builds."""
     from raft_amd.device import DeviceBatch
     rng = np.random.default_rng(2024)
-    variants = [0, 1, 2, 4, 0x31, 0x32, 0x34, 0x71, 0x131, 0x171, 0x271, 0x274, 0x2b1, 0x371, 0x472]
+    variants = [0, 1, 0x100, 0x101, 0x200, 0x301, 0x400]
     for it in range(60):
         n = int(rng.integers(1, 17))
         G = int(rng.integers(1, 3000))
@@ -748,7 +765,7 @@ def test_fuzz_layouts_windows_and_summaries(dev):
     import torch
     from raft_amd.device import DeviceBatch, summary_buffer_bytes
     rng = np.random.default_rng(77)
-    variants = [0, 1, 2, 4, 0x31, 0x32, 0x131, 0x171, 0x271, 0x274, 0x472]
+    variants = [0, 1, 0x100, 0x101, 0x200, 0x301, 0x400]
     for it in range(48):
         G = int(rng.integers(1, 2500))
         wide, joint, window = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
@@ -771,10 +788,11 @@ def test_fuzz_layouts_windows_and_summaries(dev):
             skw = dict(commit_lo16=torch.zeros(summary_buffer_bytes(G, bits) + 8, dtype=torch.uint8, device="cuda:0"),
                        summary_escapes=torch.zeros(2, dtype=torch.int32, device="cuda:0"),
                        summary_bits=bits, summary_base="commit" if base_kind == "commit" else None)
-        db = DeviceBatch(batch, **skw)
+        tbits = [None, 0, 8, 16, 32][int(rng.integers(5))]      # log-term arena entry width (None = full)
+        db = DeviceBatch(batch, log_term_bits=tbits, log_term_base=bool(rng.integers(2)), **skw)
         dev.fused_round(db, variant=variant)
         res = db.results()
-        case = (it, G, wide, joint, window, bits, hex(variant))
+        case = (it, G, wide, joint, window, bits, hex(variant), tbits, db.log_term_bits)
         mem = member_matrix(b)[:, :G] if joint else np.ones((b.n, G), bool)
         for f in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
             assert np.array_equal(res[f][:G].astype(np.int64), exp[f][:G].astype(np.int64)), (f, case)
@@ -785,7 +803,6 @@ def test_fuzz_layouts_windows_and_summaries(dev):
             fit = (d >= 0) & (d < esc)
             assert np.array_equal(res["commit_lo16"], np.where(fit, d, esc).astype(np.uint16)), case
             assert res["summary_escapes"] == int((~fit).sum()), case
-    dev.set_summary_width(16)
 
 
 def test_two_streams_on_one_engine(dev):
@@ -894,3 +911,216 @@ def test_sharded_exchange_one_rank_on_gpu(dev):
             ex.close()
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------
+# narrow log-term arenas, arena bounds, device-side summary consumer
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["fixed", "joint", "wide"])
+def test_narrow_log_term_arena(dev, kind):
+    """The log-term arena stored in 8-, 16- or 32-bit entries, with and without a
+    per-group base term: the decisions are those of the full-width arena (the
+    oracle always sees the original terms)."""
+    from raft_amd.device import DeviceBatch
+    for G, seed in ((1, 1), (65, 2), (40001, 3)):
+        if kind == "joint":
+            b = synth.gen_mixed(G, seed=seed)
+            kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
+            mem = member_matrix(b)
+        else:
+            b = synth.gen_fused(G, 5, seed=seed, ld=G + 3)
+            kw, mem = {}, None
+        exp = o.fused_round(*b.fused_args(), G=G, **kw)
+        for shift in (0, 1000, 70000):           # terms 1..9, then beyond one byte, then beyond two
+            s = synth.Batch(b)
+            for k in ("leader_term", "log_term"):
+                s[k] = (b[k].astype(np.int64) + shift).astype(np.int32)
+            batch = synth.widen(s)[0] if kind == "wide" else s
+            for bits, base in ((None, False), (0, False), (0, True), (8, True), (16, True), (32, False), (32, True)):
+                if kind != "wide" and bits == 32 and not base:
+                    continue                     # the compact layout's own width
+                db = DeviceBatch(batch, log_term_bits=bits, log_term_base=base)
+                if base and bits == 0:
+                    assert db.log_term_bits == 8          # differences inside a group are tiny
+                if not base and bits == 0:
+                    assert db.log_term_bits == (8 if shift == 0 else 16 if shift == 1000 else (64 if kind == "wide" else 32))
+                dev.fused_round(db)
+                res = db.results()
+                case = (kind, G, shift, bits, base, db.log_term_bits)
+                assert np.array_equal(res["commit"], exp["commit"]), case
+                assert np.array_equal(res["status"], exp["status"]), case
+                assert np.array_equal(res["elected"], exp["elected"]), case
+                dc = DeviceBatch(batch, log_term_bits=bits, log_term_base=base)
+                dev.commit_advance(dc)
+                assert np.array_equal(dc.results()["commit"], exp["commit"]), case
+    from raft_amd.device import encode_log_terms
+    with pytest.raises(ValueError):
+        encode_log_terms(np.array([1, 300], np.int32), bits=8)
+    with pytest.raises(ValueError):
+        encode_log_terms(np.array([-1, 3], np.int32), bits=16)
+
+
+@pytest.mark.parametrize("kind", ["fixed", "joint", "wide"])
+def test_bad_log_offsets_are_a_status_bit_not_a_fault(dev, kind):
+    """Device launches cannot validate log_off on the host.  Offsets that run
+    backwards or point past the arena (log_terms) must not be dereferenced: the
+    group gets RQ_ST_BAD_CSR and keeps its commitIndex, every other group is
+    unaffected."""
+    import ctypes as C
+    import torch
+    from raft_amd.device import DeviceBatch
+    G = 30001
+    b = synth.gen_mixed(G, seed=8) if kind == "joint" else synth.gen_fused(G, 5, seed=8)
+    kw = dict(old_mask=b.old_mask, new_mask=b.new_mask) if kind == "joint" else {}
+    exp = o.fused_round(*b.fused_args(), G=G, **kw)
+    off = b.log_off.copy()
+    rng = np.random.default_rng(4)
+    bad_back = rng.choice(np.arange(1, G - 1), 200, replace=False)
+    off[bad_back] = off[bad_back + 1] + 5                 # group g: beg > end; group g-1: end beyond its real end
+    huge = rng.choice(np.arange(1, G - 1), 50, replace=False)
+    off[huge] = 0xFFFFFF00                                # far beyond the arena
+    bb = synth.Batch(b)
+    bb["log_off"] = off
+    batch = synth.widen(bb)[0] if kind == "wide" else bb
+    db = DeviceBatch(batch)
+    dev.fused_round(db)
+    res = db.results()
+    o64 = off.astype(np.int64)
+    total = b.log_term.size
+    ok = (o64[:-1] <= o64[1:]) & (o64[1:] <= total)
+    assert (~ok).sum() >= 250
+    st = res["status"]
+    assert ((st & 4) != 0).tolist() == (~ok).tolist()
+    assert np.array_equal(res["commit"][~ok], b.commit[:G][~ok])           # no advance through a bad slice
+    # groups whose own slice is intact and unchanged decide as before
+    same = ok & (o64[:-1] == b.log_off[:-1]) & (o64[1:] == b.log_off[1:])
+    assert same.sum() > G // 2
+    assert np.array_equal(res["commit"][same], exp["commit"][same])
+    assert np.array_equal(res["status"][same], exp["status"][same])
+    for f in ("grant_mask", "stepdown_mask", "elected", "max_term"):       # the vote side never looks at the log
+        assert np.array_equal(res[f], exp[f]), f
+    # an arena length that cuts the real arena short: the tail groups are flagged, nothing past it is read
+    short = DeviceBatch(synth.widen(b)[0] if kind == "wide" else b)
+    short.log_terms = total // 2
+    dev.fused_round(short)
+    r2 = short.results()
+    cut = b.log_off[1:].astype(np.int64) > total // 2
+    assert ((r2["status"] & 4) != 0).tolist() == cut.tolist()
+    assert np.array_equal(r2["commit"][~cut], exp["commit"][~cut])
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_append_check_windows_narrow_arenas_and_bad_offsets(dev, wide):
+    """rq_append_check_dev with follower logs kept as windows (flog_base), in narrow
+    entries with a per-group base term, and with broken offsets."""
+    import torch
+    from raft_amd.device import encode_log_terms
+    dt, tdt = (np.int64, torch.int64) if wide else (np.int32, torch.int32)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    for n, G, ld, adv in ((5, 20011, 20096, False), (3, 4097, 4097, True), (16, 1000, 1000, False)):
+        b = synth.gen_append(G, n, seed=n + G, ld=ld, adversarial=adv)
+        args, kw = _append_args(b)
+        exp = o.append_check(*args, **kw)
+        for window, bits, base in ((False, 8, False), (True, 0, False), (True, 16, True), (False, 32, True)):
+            w = synth.window_flogs(b) if window else b
+            if base:      # per-group base: the smallest term any follower of the group holds (0 for none)
+                tb = np.zeros(G, np.int64)
+                off = w.flog_off.astype(np.int64)
+                for p in range(n):
+                    for g in range(0, G, max(1, G // 400)):          # exact minimum for a sample, 0 elsewhere
+                        sl = w.flog_term[off[p * ld + g]: off[p * ld + g + 1]]
+                        if sl.size:
+                            tb[g] = min(tb[g], int(sl.min())) if p else int(sl.min())
+                tb = np.minimum(tb, 1)
+                grp = np.repeat(np.arange(n * ld) % ld, np.diff(off))
+                arena = w.flog_term.astype(np.int64) - tb[np.minimum(grp, G - 1)]
+            else:
+                tb, arena = None, w.flog_term.astype(np.int64)
+            enc, ebits, _ = encode_log_terms(arena.astype(dt), bits=bits)
+            t = dict(active_mask=up(b.active_mask.view(np.int16)), follower_term=up(b.follower_term.astype(dt)),
+                     leader_term=up(b.leader_term.astype(dt)), prev_log_index=up(b.prev_log_index.astype(dt)),
+                     prev_log_term=up(b.prev_log_term.astype(dt)), n_new=up(b.n_new.astype(dt)),
+                     flog_off=up(w.flog_off.view(np.int32)), flog_term=up(enc if enc.size else np.zeros(1, enc.dtype)),
+                     follower_term_out=torch.zeros((n, ld), dtype=tdt, device="cuda:0"),
+                     success_mask=torch.zeros(G, dtype=torch.int16, device="cuda:0"),
+                     stepdown_mask=torch.zeros(G, dtype=torch.int16, device="cuda:0"),
+                     match_index=up(b.match_index.astype(dt)), next_index=up(b.next_index.astype(dt)),
+                     status=torch.zeros(G, dtype=torch.uint8, device="cuda:0"))
+            if window:
+                t["flog_base"] = up(w.flog_base.astype(dt))
+            if tb is not None:
+                t["flog_term_base"] = up(tb.astype(dt))
+            dev.append_check(t, G, n, ld, flog_term_bits=ebits, flog_terms=enc.size)
+            torch.cuda.synchronize()
+            case = (n, G, adv, window, bits, base, ebits)
+            act = ((b.active_mask[None, :].astype(np.int64) >> np.arange(n)[:, None]) & 1).astype(bool)
+            assert np.array_equal(t["success_mask"].cpu().numpy().view(np.uint16), exp["success_mask"]), case
+            assert np.array_equal(t["stepdown_mask"].cpu().numpy().view(np.uint16), exp["stepdown_mask"]), case
+            assert np.array_equal(t["status"].cpu().numpy(), exp["status"]), case
+            assert np.array_equal(t["follower_term_out"].cpu().numpy()[:, :G][act], exp["follower_term"][:, :G][act]), case
+            assert np.array_equal(t["match_index"].cpu().numpy()[:, :G], exp["match_index"][:, :G]), case
+            assert np.array_equal(t["next_index"].cpu().numpy()[:, :G], exp["next_index"][:, :G]), case
+    # broken offsets: flagged, never dereferenced
+    b = synth.gen_append(5000, 5, seed=77)
+    off = b.flog_off.copy()
+    off[3::7] = 0xFFFFFFF0
+    t = dict(follower_term=up(b.follower_term.astype(dt)), leader_term=up(b.leader_term.astype(dt)),
+             prev_log_index=up(b.prev_log_index.astype(dt)), prev_log_term=up(b.prev_log_term.astype(dt)),
+             flog_off=up(off.view(np.int32)), flog_term=up(b.flog_term.astype(dt)),
+             follower_term_out=torch.zeros((5, 5000), dtype=tdt, device="cuda:0"),
+             success_mask=torch.zeros(5000, dtype=torch.int16, device="cuda:0"),
+             stepdown_mask=torch.zeros(5000, dtype=torch.int16, device="cuda:0"),
+             status=torch.zeros(5000, dtype=torch.uint8, device="cuda:0"))
+    dev.append_check(t, 5000, 5, 5000)
+    torch.cuda.synchronize()
+    o64 = off.astype(np.int64)
+    slot_ok = ((o64[:-1] <= o64[1:]) & (o64[1:] <= b.flog_term.size)).reshape(5, 5000)
+    st = t["status"].cpu().numpy()
+    assert ((st & 4) != 0).tolist() == (~slot_ok.all(axis=0)).tolist()
+    ok_mask = t["success_mask"].cpu().numpy().view(np.uint16)
+    for p in range(5):
+        assert not ((ok_mask >> p) & 1)[~slot_ok[p]].any()
+
+
+def test_summary_consumer_applies_advances_on_the_device(dev):
+    """One rank: rounds write advance-coded summaries, the exchange gathers them, the
+    device-side consumer adds them to its replica of commitIndex with no host read
+    in between.  After four rounds the replica holds the start value plus every
+    advance that fitted the summary width; escapes are counted and leave the entry
+    alone."""
+    import torch
+    from raft_amd.device import DeviceBatch
+    from raft_amd.sharded import SummaryConsumer, SummaryExchange
+    G = 50021
+    for mode, bits in (("u8", 8), ("u4", 4), ("u16", 16)):
+        ex = SummaryExchange(G, torch.device("cuda:0"), depth=2, mode=mode, rounds=2)
+        start = np.arange(G, dtype=np.int32)[None, :] * 3
+        cons = SummaryConsumer(ex, initial=torch.from_numpy(start))
+        esc = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+        expect = start[0].astype(np.int64).copy()
+        n_esc, keep = 0, []
+        for it in range(4):
+            slot, sub = (it // 2) % 2, it % 2
+            bb = synth.gen_fused(G, 5, seed=40 + it)
+            if it == 2:
+                bb["commit"][::50] -= 400          # advances of 400 and more: beyond 4 and 8 bits
+            e = o.fused_round(*bb.fused_args(), G=G)
+            adv = e["commit"].astype(np.int64) - bb["commit"][:G]
+            fit = adv < (1 << bits) - 1
+            expect += np.where(fit, adv, 0)
+            n_esc += int((~fit).sum())
+            db = DeviceBatch(bb, commit_lo16=ex.commit_view(slot, sub), elected_bits=ex.bits_view(slot, sub),
+                             summary_escapes=esc, summary_bits=ex.bits, summary_base="commit")
+            keep.append(db)
+            if sub == 0:
+                ex.begin(slot)
+            dev.fused_round(db)
+            if sub == 1:
+                ex.exchange(slot)
+                cons.consume(slot)
+        torch.cuda.synchronize()
+        assert np.array_equal(cons.replica.cpu().numpy()[0].astype(np.int64), expect), mode
+        assert int(cons.escapes.cpu()[0]) == n_esc == int(esc.cpu()[0]), mode
+        assert (n_esc > 0) == (bits < 16)
+        cons.close()
+        ex.close()

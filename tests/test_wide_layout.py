@@ -209,7 +209,7 @@ def test_oracle64_adversarial_extremes_against_bruteforce():
 
 
 # ---------------------------------------------------------------------------
-# GPU: rq_round64 (host buffers) and rq_round64_dev (device buffers)
+# GPU: rq_round64 (host buffers) and rq_round_dev with RQ_LAYOUT_I64 (device buffers)
 # ---------------------------------------------------------------------------
 def engine_round64(engine):
     def fn(what, **kw):
@@ -284,7 +284,7 @@ def dev():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("variant", [0, 0x001, 0x131, 0x171, 0x231, 0x471])
+@pytest.mark.parametrize("variant", [0, 0x001, 0x100, 0x201, 0x400])
 def test_gpu_wide_device_launch(dev, variant):
     import torch
     from raft_amd.device import DeviceBatch
@@ -437,7 +437,7 @@ def test_gpu_wide_follower_clamp(engine):
 
 @pytest.mark.gpu
 def test_gpu_wide_plan_equals_direct_launch(dev):
-    """rq_plan_round64 + rq_plan_launch against rq_round64_dev, fixed and joint, every `what`."""
+    """rq_plan_round + rq_plan_launch against rq_round_dev in the wide layout, fixed and joint, every `what`."""
     from raft_amd.device import DeviceBatch
     from raft_amd._lib import RqError
     for b in (synth.gen_fused(50021, 5, seed=15), synth.gen_mixed(20003, seed=16)):
@@ -447,7 +447,7 @@ def test_gpu_wide_plan_equals_direct_launch(dev):
             d1, d2 = DeviceBatch(w), DeviceBatch(w)
             for _ in range(2):                       # the second launch reuses the cached plan
                 dev.round64(d1, what)
-            dev.round64_direct(d2, what)
+            dev.round_direct(d2, what)
             r1, r2 = d1.results(), d2.results()
             for f in OUT_FIELDS:
                 assert np.array_equal(r1[f], r2[f]), (f, what)
@@ -455,5 +455,11 @@ def test_gpu_wide_plan_equals_direct_launch(dev):
                 assert_same(r1, exp, w)
     import ctypes as C
     plan = C.c_void_p()
-    assert dev._l.rq_plan_round64(dev._h, 0, 0, 10, 3, 10, *([None] * 24), C.byref(plan)) == -1   # no decision
-    assert dev._l.rq_plan_round64(dev._h, 0, 1, 10, 3, 10, *([None] * 24), C.byref(plan)) == -1   # null planes
+    d = dev.describe(d1, 3)
+    for field, bad in (("what", 0), ("what", 4), ("match", None), ("layout", 6), ("struct_size", 8), ("n", 17),
+                       ("log_term_bits", 12), ("reserved", 1)):
+        e = type(d).from_buffer_copy(d)
+        setattr(e, field, bad)
+        assert dev._l.rq_plan_round(dev._h, C.byref(e), C.byref(plan)) == -1, field
+        assert dev._l.rq_round_dev(dev._h, None, C.byref(e)) == -1, field
+    assert dev._l.rq_plan_round(dev._h, C.byref(d), None) == -1

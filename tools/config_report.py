@@ -145,12 +145,8 @@ for b in ab:
 
 def append_step(i):
     t = dab[i % len(dab)]
-    p = lambda k: t[k].data_ptr()
-    rc = eng._l.rq_append_check_dev(eng._h, torch.cuda.current_stream().cuda_stream, G, n, G,
-                                    p("active_mask"), p("follower_term"), p("leader_term"), p("prev_log_index"),
-                                    p("prev_log_term"), p("n_new"), p("flog_off"), p("flog_term"), p("ft_out"),
-                                    p("ok"), p("sd"), p("match_index"), p("next_index"), p("st"))
-    assert rc == 0, rc
+    eng.append_check(dict(t, follower_term_out=t["ft_out"], success_mask=t["ok"], stepdown_mask=t["sd"],
+                          status=t["st"]), G, n, G)
 
 
 sec = timed(append_step, 200, 20)
