@@ -12,7 +12,7 @@ build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h $(CSRC)/rq
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-raft_amd/librq.so: build/rq_kernels.o build/rq_kernels64.o build/rq_engine.o build/rq_comm.o
+raft_amd/librq.so: build/rq_kernels.o build/rq_kernels64.o build/rq_engine.o build/rq_comm.o build/rq_noalloc.o
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -ldl -o $@
 
 HOST = $(CSRC)/host

@@ -357,6 +357,32 @@ int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d);
 
 int rq_stream_sync(rq_engine *e, void *stream);
 
+/* rq_fused_round for callers that cannot allocate.  It has no counterpart in the
+ * reference: it exists for callers that may not call an allocator (tight
+ * serving loops, harnesses that forbid hipMalloc) and therefore cannot create
+ * an rq_engine, whose staging memory comes from hipMalloc.  Same arguments,
+ * rules and outputs as rq_fused_round, but no engine: the round is staged
+ * through a fixed RQ_NOALLOC_SCRATCH_BYTES array inside the library's device
+ * image (every process holds one copy per GPU it uses until it ends) and runs on
+ * `stream` (NULL = the default stream) of `device`; the call returns when the
+ * outputs are in the caller's buffers.  It calls no hipMalloc / hipFree or any
+ * other allocating routine.  A shape whose staging image (16n + 30 bytes per
+ * group plus 4 per log entry) exceeds the array is refused with RQ_E_RANGE:
+ * with n = 5 and logs of 8 entries about 110 000 groups.  Calls on one GPU share the
+ * array: within a process they are serialised by the library; the array keeps
+ * the previous call's contents, every byte a call reads it has written first. */
+#define RQ_NOALLOC_SCRATCH_BYTES (16u << 20)
+int rq_fused_round_noalloc(int device, void *stream, uint32_t G, uint32_t n, uint32_t ld,
+                           const int32_t *match, const int32_t *commit,
+                           const int32_t *leader_term, const uint32_t *log_off,
+                           const int32_t *log_term,
+                           const int32_t *voter_term, const int32_t *voted_for,
+                           const int32_t *voter_last_log_term, const int32_t *cand_term,
+                           const int32_t *cand_id,
+                           int32_t *commit_out, int32_t *voter_term_out,
+                           uint16_t *grant_mask, uint16_t *stepdown_mask,
+                           uint8_t *elected, int32_t *max_term, uint8_t *status_out);
+
 /* ---- wide layout on host buffers ----------------------------------------- *
  * rq_fused_round / rq_follower_clamp / rq_append_check over int64_t planes
  * (the 64-bit staging buffers are allocated by the first call and kept).
