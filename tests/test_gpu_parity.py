@@ -338,8 +338,9 @@ def test_full_size_1m_by_5(engine):
 def test_full_size_8m_by_5_sharded_equals_unsharded(dev):
     """8M groups x 5 peers (the 8-GPU configuration's total) on one GPU: one launch
     over all groups against eight block-partitioned shard launches (what eight
-    ranks would run), bit for bit, plus size-independent properties; the last
-    shard is also checked against the oracle."""
+    ranks would run), bit for bit, plus size-independent properties; every
+    shard is also checked against the oracle (odd shards keep their log arena in
+    narrow entries, as the benchmark does)."""
     from raft_amd.device import DeviceBatch
     from raft_amd.sharded import shard_bounds
     G, n, R = 8 << 20, 5, 8
@@ -359,21 +360,42 @@ def test_full_size_8m_by_5_sharded_equals_unsharded(dev):
             sb[k] = b[k][g0:g1].copy()
         sb["log_term"] = b.log_term[off[g0]:off[g1]].copy()
         sb["log_off"] = (off[g0:g1 + 1] - off[g0]).astype(np.uint32)
-        d = DeviceBatch(sb)
+        d = DeviceBatch(sb, log_term_bits=0 if r % 2 else None)
         dev.fused_round(d)
         s = d.results()
         for f in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
             assert np.array_equal(s[f], w[f][g0:g1]), (f, r)
         assert np.array_equal(s["voter_term"], w["voter_term"][:, g0:g1]), r
         assert np.array_equal(s["elected_bits"], w["elected_bits"][g0 // 64:g1 // 64]), r
-        if r == R - 1:
-            exp = o.fused_round(*sb.fused_args())
-            assert np.array_equal(s["commit"], exp.commit) and np.array_equal(s["elected"], exp.elected)
-            assert np.array_equal(s["voter_term"], exp.voter_term)
+        exp = o.fused_round(*sb.fused_args())
+        assert np.array_equal(s["commit"], exp.commit), r
+        assert_vote_equal(synth.Batch(s), exp, g1 - g0)
     N = np.sort(b.match, axis=0)[2]
     assert (w["commit"] >= b.commit).all() and ((w["commit"] == b.commit) | (w["commit"] == N)).all()
     assert (w["voter_term"] == np.maximum(b.voter_term, b.cand_term[None, :])).all()
     assert 0.2 < w["elected"].mean() < 0.9 and 0.1 < (w["commit"] != b.commit).mean() < 0.6
+
+
+def test_full_size_1m_mixed_sizes_and_joint_consensus(dev):
+    """The mixed configuration at its stated size: 1M groups of 3-9 peers, 10 % of them
+    in joint consensus, Zipf(1.2) log lengths up to 4096 (a 0.9 G-entry arena), the
+    member-mask kernel against the oracle on every group; then the same batch with
+    the arena in 8-bit entries and per-group base terms."""
+    from raft_amd.device import DeviceBatch
+    G = 1 << 20
+    b = synth.gen_mixed(G, seed=2025)
+    exp = o.fused_round(*b.fused_args(), G=G, old_mask=b.old_mask, new_mask=b.new_mask)
+    mem = member_matrix(b)
+    for kw in ({}, dict(log_term_bits=0, log_term_base=True)):
+        db = DeviceBatch(b, **kw)
+        dev.fused_round(db)
+        res = db.results()
+        _check_dev(res, exp, G, mem)
+        del db
+    assert res["commit"].shape == (G,) and (res["commit"] >= b.commit).all()
+    joint = b.old_mask != b.new_mask
+    assert 0.05 < joint.mean() < 0.15 and 0.05 < (res["commit"] != b.commit).mean() < 0.7
+    assert 0.1 < res["elected"].mean() < 0.9 and np.diff(b.log_off.astype(np.int64)).max() == 4096
 
 
 # ---------------------------------------------------------------------------

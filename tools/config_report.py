@@ -79,13 +79,21 @@ out.append(rate("C2 10k x 3 commit only (latency-bound)", b.G, 4 * 3 + 20, sec,
 
 # C3 and its split kernels: 1M x 5
 G, n, S = 1 << 20, 5, 12
-sets = [DeviceBatch(synth.gen_fused(G, n, seed=77 + s, ld=G + 256), dev) for s in range(S)]
-sec = timed(lambda i: eng.fused_round(sets[i % S]), 300, 30)
-out.append(rate("C3 1M x 5 fused round", G, 137, sec))
-sec = timed(lambda i: eng.vote_tally(sets[i % S]), 300, 30)
-out.append(rate("1M x 5 vote tally only", G, 97, sec))
-sec = timed(lambda i: eng.commit_advance(sets[i % S]), 300, 30)
-out.append(rate("1M x 5 commit advance only", G, 40, sec))
+hosts = [synth.gen_fused(G, n, seed=77 + s, ld=G + 256) for s in range(S)]
+for arena, bits in (("int32 log-term arena", None), ("8-bit log-term arena entries", 0)):
+    sets = [DeviceBatch(b, dev, log_term_bits=bits) for b in hosts]
+    for s_ in sets:                       # plans built, buffers touched
+        eng.fused_round(s_); eng.commit_advance(s_); eng.vote_tally(s_)
+    sec = timed(lambda i: eng.fused_round(sets[i % S]), 300, 30)
+    out.append(rate("C3 1M x 5 fused round, " + arena, G, 137, sec))
+    sec = timed(lambda i: eng.commit_advance(sets[i % S]), 300, 30)
+    out.append(rate("1M x 5 commit advance only, " + arena, G, 40, sec))
+    if bits is None:
+        sec = timed(lambda i: eng.vote_tally(sets[i % S]), 300, 30)
+        out.append(rate("1M x 5 vote tally only", G, 97, sec))
+    del sets
+    torch.cuda.empty_cache()
+del hosts
 
 # host-buffer entry point (PCIe and pageable staging inclusive) on one set
 hb = synth.gen_fused(G, n, seed=5)
@@ -104,15 +112,18 @@ with QuorumEngine(max_groups=G, max_slots=n, max_log_terms=int(hb.log_term.size)
         qe.fused_round(*pinned)
     sec = (time.perf_counter() - t0) / 3
 out.append(rate("same, inputs in rq_host_alloc (page-locked) memory; outputs pageable", G, 137, sec))
-del sets
 torch.cuda.empty_cache()
 
 # C4 at one GPU: 8M x 5
 G8 = 8 << 20
-sets = [DeviceBatch(synth.gen_fused(G8, n, seed=300 + s, ld=G8 + 256), dev) for s in range(2)]
-sec = timed(lambda i: eng.fused_round(sets[i % 2]), 40, 5)
-out.append(rate("C4 8M x 5 fused round on ONE GPU (2 sets, 2.8 GB)", G8, 137, sec))
-del sets
+hosts = [synth.gen_fused(G8, n, seed=300 + s, ld=G8 + 256) for s in range(2)]
+for arena, bits in (("int32 log-term arena", None), ("8-bit log-term arena entries", 0)):
+    sets = [DeviceBatch(b, dev, log_term_bits=bits) for b in hosts]
+    sec = timed(lambda i: eng.fused_round(sets[i % 2]), 40, 5)
+    out.append(rate("C4 8M x 5 fused round on ONE GPU (2 sets, 2.8 GB), " + arena, G8, 137, sec))
+    del sets
+    torch.cuda.empty_cache()
+del hosts
 torch.cuda.empty_cache()
 
 # C5: 1M mixed 3-9 + joint, Zipf logs (arena shared between the sets)
@@ -123,37 +134,64 @@ for s in range(1, 8):
 mem = (first.old_mask | first.new_mask).astype(np.int64)
 members = float(sum((mem >> p) & 1 for p in range(16)).mean())
 sec = timed(lambda i: eng.fused_round(sets[i % 8]), 200, 20)
-out.append(rate("C5 1M mixed 3-9 peers + 10% joint, Zipf logs", G, 20 * members + 41, sec,
+out.append(rate("C5 1M mixed 3-9 peers + 10% joint, Zipf logs, int32 log-term arena", G, 20 * members + 41, sec,
+                dict(mean_member_slots=members, arena_entries=int(first.log_term.size))))
+del sets
+torch.cuda.empty_cache()
+sets = [DeviceBatch(first, dev, log_term_bits=0)]
+for s in range(1, 8):
+    sets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), dev, share_log_with=sets[0]))
+sec = timed(lambda i: eng.fused_round(sets[i % 8]), 200, 20)
+out.append(rate("C5 1M mixed 3-9 peers + 10% joint, Zipf logs, 8-bit log-term arena entries", G, 20 * members + 41, sec,
                 dict(mean_member_slots=members, arena_entries=int(first.log_term.size))))
 del sets
 torch.cuda.empty_cache()
 
-# AppendEntries consistency batch: 1M x 5
-import ctypes as C
-ab = [synth.gen_append(G, n, seed=900 + s) for s in range(6)]
-dab = []
-for b in ab:
-    t = {k: torch.from_numpy(np.ascontiguousarray(b[k].view(np.int32) if b[k].dtype == np.uint32 else
-                                                  (b[k].view(np.int16) if b[k].dtype == np.uint16 else b[k]))).to(dev)
-         for k in ("active_mask", "follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
-                   "flog_off", "flog_term", "match_index", "next_index")}
-    t["ft_out"] = torch.zeros_like(t["follower_term"])
-    t["ok"] = torch.zeros(G, dtype=torch.int16, device=dev); t["sd"] = torch.zeros(G, dtype=torch.int16, device=dev)
-    t["st"] = torch.zeros(G, dtype=torch.uint8, device=dev)
-    dab.append(t)
+# AppendEntries consistency batch: 1M groups, 4 followers each
+from raft_amd.device import encode_log_terms
 
 
-def append_step(i):
-    t = dab[i % len(dab)]
-    eng.append_check(dict(t, follower_term_out=t["ft_out"], success_mask=t["ok"], stepdown_mask=t["sd"],
-                          status=t["st"]), G, n, G)
+def append_sets(n, use_mask, term_bits, window, count=6):
+    """Device tensors of `count` AppendEntries batches.  n = 5 with the leader's own slot
+    masked out (holes in every plane line), or n = 4 follower planes and no mask."""
+    out = []
+    for s_ in range(count):
+        b = synth.gen_append(G, n, seed=900 + s_)
+        if window:
+            b = synth.window_flogs(b)
+        enc, bits, _ = encode_log_terms(b.flog_term, bits=term_bits)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        t = {k: up(b[k]) for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
+                                   "match_index", "next_index")}
+        t["flog_off"] = up(b.flog_off.view(np.int32))
+        t["flog_term"] = up(enc)
+        if use_mask:
+            t["active_mask"] = up(b.active_mask.view(np.int16))
+        if window:
+            t["flog_base"] = up(b.flog_base)
+        t["follower_term_out"] = torch.zeros_like(t["follower_term"])
+        t["success_mask"] = torch.zeros(G, dtype=torch.int16, device=dev)
+        t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device=dev)
+        t["status"] = torch.zeros(G, dtype=torch.uint8, device=dev)
+        t["_bits"], t["_terms"] = bits, int(enc.size)
+        out.append(t)
+    return out
 
 
-sec = timed(append_step, 200, 20)
-act = float(sum((ab[0].active_mask.astype(np.int64) >> p) & 1 for p in range(n)).mean())
 # per active follower: term, prevIdx, prevTerm, off, gathered term, n_new, match, next in; term', match', next' out
-out.append(rate("AppendEntries consistency batch 1M x 5 (4 followers per group)", G, 44 * act + 4 + 2 + 2 + 2, sec,
-                dict(active_followers=act)))
+APPEND_ALG = 44 * 4 + 4 + 2 + 2 + 2
+for label, n_planes, use_mask, term_bits, window in (
+        ("5 slot planes, leader's slot masked out, int32 follower logs", 5, True, 32, False),
+        ("5 slot planes, leader's slot masked out, 8-bit follower-log entries", 5, True, 0, False),
+        ("4 follower planes (no mask, no holes), 8-bit entries", 4, False, 0, False),
+        ("4 follower planes, 8-bit entries, logs windowed to the suffix around prevLogIndex", 4, False, 0, True)):
+    dab = append_sets(n_planes, use_mask, term_bits, window)
+    sec = timed(lambda i: eng.append_check(dab[i % len(dab)], G, n_planes, G, flog_term_bits=dab[i % len(dab)]["_bits"],
+                                           flog_terms=dab[i % len(dab)]["_terms"]), 200, 20)
+    out.append(rate("AppendEntries consistency batch 1M groups x 4 followers: " + label, G, APPEND_ALG, sec,
+                    dict(term_bits=dab[0]["_bits"], arena_entries=dab[0]["_terms"])))
+    del dab
+    torch.cuda.empty_cache()
 
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "configs.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)

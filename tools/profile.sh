@@ -6,7 +6,7 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 60 --warmup 10 $*"
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 60 --warmup 10 $*"
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1 || { echo "kernel-trace pass failed"; tail -5 $OUT/kt.log; exit 1; }
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \

@@ -69,6 +69,8 @@ if "FETCH_SIZE" in avg and "WRITE_SIZE" in avg:
         print("  writes from request counters: %.1f MB" % (wr_raw / 1e6))
     print("  total: %.1f MB" % ((rd + wr) / 1e6))
     import json
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_hash          # ties the figure to the kernel source it was measured on
     json.dump({"hbm_bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
-               "kernel": dom, "source": os.path.basename(root)},
+               "kernel": dom, "source": os.path.basename(root), "kernel_source_hash": kernel_source_hash()},
               open(os.path.join(root, "traffic.json"), "w"))
