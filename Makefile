@@ -8,7 +8,7 @@ CSRC     = raft_amd/csrc
 
 all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli examples/rq_bench
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h $(CSRC)/rq_append_impl.h include/rq.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/rq_kernels.h $(CSRC)/rq_round_impl.h $(CSRC)/rq_append_impl.h $(CSRC)/rq_groups_impl.h include/rq.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
@@ -16,8 +16,8 @@ raft_amd/librq.so: build/rq_kernels.o build/rq_kernels64.o build/rq_engine.o bui
 	$(HIPCC) -shared -fPIC --offload-arch=$(ARCH) $^ -ldl -o $@
 
 HOST = $(CSRC)/host
-raft_amd/libraft_host.so: $(HOST)/raft_host.cpp $(HOST)/raft_host_capi.cpp $(HOST)/raft_host.hpp include/rq.h raft_amd/librq.so
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -Wextra $(HOST)/raft_host.cpp $(HOST)/raft_host_capi.cpp \
+raft_amd/libraft_host.so: $(HOST)/raft_host.cpp $(HOST)/raft_host_resident.cpp $(HOST)/raft_host_capi.cpp $(HOST)/raft_host.hpp include/rq.h raft_amd/librq.so
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Wextra $(HOST)/raft_host.cpp $(HOST)/raft_host_resident.cpp $(HOST)/raft_host_capi.cpp \
 	    -Lraft_amd -lrq -Wl,-rpath,'$$ORIGIN' -o $@
 
 oracle/librq_oracle.so: oracle/raft_oracle.c oracle/raft_oracle.h

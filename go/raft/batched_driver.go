@@ -3,6 +3,7 @@ package raft
 import (
 	"errors"
 	"math"
+	"strconv"
 )
 
 // Group is one Raft group as the driver sees it: its members in slot order,
@@ -48,6 +49,38 @@ var wide = layout[int64]{math.MaxInt64, math.MinInt64, math.MinInt64,
 	func(v int) bool { return true }}
 
 var errRange = errors.New("raft: value outside the range of the engine layout")
+
+// GroupStatus names a group whose round hit a condition that is a runtime panic
+// in the per-node methods: Status carries the RQ_ST_* bits (2: a voter reached
+// lastEntry(log) with an empty log, raft.go:204/:235; 1: the leader's quorum index
+// lies outside its log, the indexing convention of raft.go:151).
+type GroupStatus struct {
+	Group  int
+	Status uint8
+}
+
+// PanicError is returned by Step when some groups were flagged. The round has
+// been applied for every group; a flagged group keeps what the reference had
+// done before its panic (voters' terms raised and roles set, raft.go:219-221, no
+// grant from the panicking voter, no commit advance).
+type PanicError struct{ Groups []GroupStatus }
+
+func (e *PanicError) Error() string {
+	return "raft: " + strconv.Itoa(len(e.Groups)) + " group(s) hit a condition that panics in the per-node methods"
+}
+
+func flagged(status []uint8) error {
+	var fl []GroupStatus
+	for g, st := range status {
+		if st != 0 {
+			fl = append(fl, GroupStatus{g, st})
+		}
+	}
+	if fl == nil {
+		return nil
+	}
+	return &PanicError{fl}
+}
 
 // BatchedDriver evaluates one quorum round for every registered group in one
 // GPU launch and applies the decisions to the Go objects.
@@ -168,6 +201,13 @@ func apply[T word](d *BatchedDriver, b *roundBuffers[T]) {
 // Step runs one fused round and applies it. The compact layout is tried first;
 // if some value does not fit int32 the round runs in the wide layout. Groups
 // of different sizes run through the member-mask round (old = new = members).
+// A *PanicError lists the groups where the per-node methods would have panicked
+// (a cluster straight from NewNode has empty logs, raft.go:87, and panics in
+// RequestVoteRPC); the round is applied either way.
+//
+// Step flattens every Node and moves the whole image over PCIe both ways: fine
+// for thousands of groups, milliseconds for a million. ResidentDriver keeps the
+// image in HBM and moves only the groups the host touched.
 func (d *BatchedDriver) Step() error {
 	b, err := flatten(d, compact)
 	if err == errRange {
@@ -180,7 +220,7 @@ func (d *BatchedDriver) Step() error {
 		}
 		apply(d, w)
 		d.LastStepWide = true
-		return nil
+		return flagged(w.status)
 	}
 	if err != nil {
 		return err
@@ -190,7 +230,7 @@ func (d *BatchedDriver) Step() error {
 	}
 	apply(d, b)
 	d.LastStepWide = false
-	return nil
+	return flagged(b.status)
 }
 
 // Close releases the GPU engine.

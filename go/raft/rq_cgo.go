@@ -35,11 +35,38 @@ func (e *rqEngine) close() {
 	}
 }
 
-func i32(p []int32) *C.int32_t   { return (*C.int32_t)(unsafe.Pointer(&p[0])) }
-func u32(p []uint32) *C.uint32_t { return (*C.uint32_t)(unsafe.Pointer(&p[0])) }
-func u16(p []uint16) *C.uint16_t { return (*C.uint16_t)(unsafe.Pointer(&p[0])) }
-func u8(p []uint8) *C.uint8_t    { return (*C.uint8_t)(unsafe.Pointer(&p[0])) }
-func i64(p []int64) *C.int64_t   { return (*C.int64_t)(unsafe.Pointer(&p[0])) }
+// Slice -> C pointer; an empty slice (a driver with no groups) is NULL, which the
+// entry points accept together with G = 0.
+func i32(p []int32) *C.int32_t {
+	if len(p) == 0 {
+		return nil
+	}
+	return (*C.int32_t)(unsafe.Pointer(&p[0]))
+}
+func u32(p []uint32) *C.uint32_t {
+	if len(p) == 0 {
+		return nil
+	}
+	return (*C.uint32_t)(unsafe.Pointer(&p[0]))
+}
+func u16(p []uint16) *C.uint16_t {
+	if len(p) == 0 {
+		return nil
+	}
+	return (*C.uint16_t)(unsafe.Pointer(&p[0]))
+}
+func u8(p []uint8) *C.uint8_t {
+	if len(p) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&p[0]))
+}
+func i64(p []int64) *C.int64_t {
+	if len(p) == 0 {
+		return nil
+	}
+	return (*C.int64_t)(unsafe.Pointer(&p[0]))
+}
 
 // fusedRound passes only flat scalar slices (no Go pointers inside them), which
 // is what the cgo pointer rules require; librq copies before it returns.

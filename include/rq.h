@@ -256,6 +256,16 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  *               below commitIndex can never be looked up: the rule needs N >
  *               commitIndex); an N below the base is RQ_ST_LOG_OOB like an N
  *               past the end.
+ *   log_len     [G], may be NULL: group g's log is then the log_len[g] entries
+ *               from log_off[g] on, wherever that lies in the arena (log_off[g+1]
+ *               is not read and the offsets need not be ordered), so a host can
+ *               leave room behind each log to grow in place and move a log that
+ *               ran out of room to free arena space (rq_groups_scatter_dev); a
+ *               log that would end past log_terms is RQ_ST_BAD_CSR.
+ *   changed_bits   may be NULL; else 1 bit per group, packed like elected_bits,
+ *               set when the round moved the group's commitIndex, stepped one of
+ *               its voters down, elected its candidate or set a status bit: the
+ *               groups a host has to look at after the round.
  *   elected_bits   may be NULL; else the elected decisions packed 1 bit per
  *               group ([ceil(G/64)] uint64, bit g%64 of word g/64): the summary
  *               vector ranks exchange in a sharded deployment.
@@ -302,6 +312,7 @@ typedef struct rq_round_desc {
     const void *match, *commit, *leader_term;
     const uint32_t *log_off;
     const void *log_term, *log_base, *log_term_base;
+    const uint32_t *log_len;    /* may be NULL */
     /* vote side */
     const void *voter_term, *voted_for, *voter_last_log_term, *cand_term, *cand_id;
     /* outputs */
@@ -311,6 +322,7 @@ typedef struct rq_round_desc {
     void *max_term;
     uint8_t *status_out;        /* may be NULL */
     uint64_t *elected_bits;     /* may be NULL */
+    uint64_t *changed_bits;     /* may be NULL */
     void *commit_summary;       /* may be NULL */
     const void *summary_base;
     uint32_t *summary_escapes;
@@ -354,6 +366,34 @@ typedef struct rq_append_desc {
     uint8_t *status_out;
 } rq_append_desc;
 int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d);
+
+/* Single groups in and out of a resident round (no counterpart in the
+ * reference: there the state IS the Go objects).  A host that keeps the planes of
+ * descriptor `d` resident and applies RPCs to a few of its Node objects between
+ * two rounds moves only those groups:
+ * rq_groups_scatter_dev overwrites group gids[r] with row r,
+ *     rows[r] = { match[n], voter_term[n], voted_for[n], voter_last_log_term[n],
+ *                 commit, leader_term, cand_term, cand_id, log_base,
+ *                 old_mask | new_mask << 16, log_off }     (4n + 7 elements)
+ * in the layout's element type, and replaces the group's log by the terms
+ * row_log_terms[row_log_off[r] .. row_log_off[r+1]) (elements; stored in the
+ * arena's entry width after subtracting log_term_base[g]).  With a log_len plane
+ * the log is written at the row's log_off (the host's choice: the old place if
+ * there is room, else free arena space) and log_off[g], log_len[g] are set;
+ * without one the row's log_off is ignored and the length must equal the group's
+ * slice.  Fields whose
+ * descriptor pointer is NULL are skipped.  A row is applied completely or not at
+ * all; row_status[r] (may be NULL) = 0, or 1 the log does not fit the group's
+ * slice, 2 a term does not fit the arena's entry width, 4 no such group.
+ * rq_groups_gather_dev packs the outputs of the listed groups:
+ *     rows_out[r] = { commit_out, max_term, voter_term_out[n] }   (n + 2 elements)
+ *     flags_out[r] = grant_mask | stepdown_mask << 16 | elected << 32 | status << 40
+ * All pointers are device pointers; both calls are enqueued on `stream`. */
+int rq_groups_scatter_dev(rq_engine *e, void *stream, const rq_round_desc *d, uint32_t count,
+                          const uint32_t *gids, const void *rows, const uint32_t *row_log_off,
+                          const void *row_log_terms, uint8_t *row_status);
+int rq_groups_gather_dev(rq_engine *e, void *stream, const rq_round_desc *d, uint32_t count,
+                         const uint32_t *gids, void *rows_out, uint64_t *flags_out);
 
 int rq_stream_sync(rq_engine *e, void *stream);
 

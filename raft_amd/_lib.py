@@ -29,11 +29,12 @@ class RoundDesc(C.Structure):
                 ("reserved", u32), ("log_terms", u64),
                 ("old_mask", vp), ("new_mask", vp),
                 ("match", vp), ("commit", vp), ("leader_term", vp), ("log_off", vp),
-                ("log_term", vp), ("log_base", vp), ("log_term_base", vp),
+                ("log_term", vp), ("log_base", vp), ("log_term_base", vp), ("log_len", vp),
                 ("voter_term", vp), ("voted_for", vp), ("voter_last_log_term", vp),
                 ("cand_term", vp), ("cand_id", vp),
                 ("commit_out", vp), ("voter_term_out", vp), ("grant_mask", vp), ("stepdown_mask", vp),
                 ("elected", vp), ("max_term", vp), ("status_out", vp), ("elected_bits", vp),
+                ("changed_bits", vp),
                 ("commit_summary", vp), ("summary_base", vp), ("summary_escapes", vp)]
 
 
@@ -76,6 +77,8 @@ PROTOTYPES = {
     # device-pointer launches: descriptors of raw addresses so torch data_ptr() ints pass through
     "rq_round_dev": [vp, vp, C.POINTER(RoundDesc)],
     "rq_plan_round": [vp, C.POINTER(RoundDesc), C.POINTER(vp)],
+    "rq_groups_scatter_dev": [vp, vp, C.POINTER(RoundDesc), u32, vp, vp, vp, vp, vp],
+    "rq_groups_gather_dev": [vp, vp, C.POINTER(RoundDesc), u32, vp, vp, vp],
     # wide layout on host buffers: what, G, m, ld, then 2 masks + 11 inputs + 7 outputs
     "rq_round64": [vp, cint, u32, u32, u32] + [vp] * 20,
     "rq_follower_clamp64": [vp, u64, vp, vp, vp, vp],

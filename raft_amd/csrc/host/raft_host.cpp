@@ -185,6 +185,21 @@ void BatchedDriver::ApplyT(std::vector<Group> &groups, const RoundBuffersT<T> &b
     }
 }
 
+template <typename T>
+void BatchedDriver::CollectFlagged(const RoundBuffersT<T> &b) {
+    flagged_.clear();
+    for (uint32_t g = 0; g < b.groups; g++)
+        if (b.status[g]) flagged_.push_back(GroupStatus{g, b.status[g]});
+}
+
+void BatchedDriver::ThrowIfFlagged() const {
+    if (flagged_.empty()) return;
+    const GroupStatus &f = flagged_.front();
+    throw GoPanic("group " + std::to_string(f.group) +
+                  ((f.status & RQ_ST_EMPTY_LOG) ? ": index out of range [-1] (lastEntry of an empty log)"
+                                                : ": index out of range (log[N] beyond the leader's log)"));
+}
+
 int BatchedDriver::Flatten(RoundBuffers &b) const { return FlattenT(groups_, slots_, b); }
 int BatchedDriver::Flatten(RoundBuffers64 &b) const { return FlattenT(groups_, slots_, b); }
 void BatchedDriver::Apply(const RoundBuffers &b) { ApplyT(groups_, b); }
@@ -227,6 +242,7 @@ int BatchedDriver::Step(int device) {
                         w.elected.data(), w.maxTerm.data(), w.status.data());
         if (rc != RQ_OK) return rc;
         Apply(w);
+        CollectFlagged(w);
         last_step_wide_ = true;
         return RQ_OK;
     }
@@ -248,6 +264,7 @@ int BatchedDriver::Step(int device) {
                             b.stepdownMask.data(), b.elected.data(), b.maxTerm.data(), b.status.data());
     if (rc != RQ_OK) return rc;
     Apply(b);
+    CollectFlagged(b);
     last_step_wide_ = false;
     return RQ_OK;
 }

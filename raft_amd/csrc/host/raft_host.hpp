@@ -32,6 +32,7 @@ struct GoPanic : std::runtime_error {
 };
 
 class BatchedDriver;
+class ResidentDriver;
 
 // raft.go:15-69.  Fields are private like the reference's unexported fields;
 // the batched driver is a friend the way it is a package member in Go.
@@ -59,10 +60,12 @@ public:
     std::vector<int64_t> &MatchIndexForTest() { return matchIndex; }
     void SeedForTest(int64_t currentTerm, int64_t votedFor, NodeType type, int64_t commitIndex);
     void SeedLogForTest(const std::vector<int64_t> &terms);
+    void AppendForTest(const std::vector<Entry> &entries) { log.insert(log.end(), entries.begin(), entries.end()); }
 
 private:
     friend Node *NewNode(int64_t, std::vector<Node *>, std::function<void(const std::string &)>);
     friend class BatchedDriver;
+    friend class ResidentDriver;
     void testToAbdicateLeadership(int64_t term);  // raft.go:212-223
 
     int64_t id = 0;
@@ -112,6 +115,15 @@ typedef RoundBuffersT<int64_t> RoundBuffers64;
 
 enum : int { kDriverOk = 0, kDriverRange = -2, kDriverShape = -1 };
 
+// A group whose round hit a condition that is a Go panic in the reference:
+// status carries the RQ_ST_* bits (RQ_ST_EMPTY_LOG: a voter reached
+// lastEntry(log) with an empty log, raft.go:204/:235; RQ_ST_LOG_OOB: the leader's
+// quorum index lies outside its log, the indexing convention of raft.go:151).
+struct GroupStatus {
+    uint32_t group;
+    uint8_t status;
+};
+
 class BatchedDriver {
 public:
     // slots = the largest group size; smaller groups are allowed (1..slots members).
@@ -130,14 +142,24 @@ public:
     // tried first; if some value does not fit int32 the round runs in the wide
     // layout instead.  Groups of different sizes run through the member-mask
     // (joint) round with old = new = the group's members.  Returns an RQ_* code.
+    //
+    // Where the reference would panic for some group (see GroupStatus) the round
+    // is still applied for every group -- a flagged group keeps what the reference
+    // had done before its panic: voters' terms raised and roles set (raft.go:219-
+    // 221), no grant from the panicking voter, no commit advance -- and the groups
+    // are listed in Flagged(); ThrowIfFlagged() turns the first one into the
+    // GoPanic a per-node call sequence would have raised.
     int Step(int device);
     bool LastStepWide() const { return last_step_wide_; }
+    const std::vector<GroupStatus> &Flagged() const { return flagged_; }
+    void ThrowIfFlagged() const;
     std::vector<Group> &Groups() { return groups_; }
 
 private:
     int EnsureEngine(int device, uint32_t groups, uint32_t slots, uint64_t log_terms);
     template <typename T> static int FlattenT(const std::vector<Group> &groups, uint32_t n, RoundBuffersT<T> &b);
     template <typename T> static void ApplyT(std::vector<Group> &groups, const RoundBuffersT<T> &b);
+    template <typename T> void CollectFlagged(const RoundBuffersT<T> &b);
     std::vector<Group> groups_;
     uint32_t slots_;
     rq_engine *engine_ = nullptr;
@@ -145,6 +167,50 @@ private:
     uint64_t engine_log_cap_ = 0;
     uint32_t engine_groups_ = 0;
     bool last_step_wide_ = false;
+    std::vector<GroupStatus> flagged_;
+};
+
+// ---- resident driver (no counterpart in the reference) ----------------------
+//
+// BatchedDriver::Step flattens every Node and moves the whole image over PCIe in
+// both directions on every call: milliseconds around a 30 us kernel.  The
+// resident driver keeps the image in HBM between rounds.  The host tells it
+// which groups it touched (MarkDirty, after applying RPCs to their Nodes); Step
+// uploads those groups only (rq_groups_scatter_dev), runs the round in place
+// (rq_plan_launch), reads the one-bit-per-group "changed" summary the kernel
+// wrote and downloads and applies only the groups whose bit is set
+// (rq_groups_gather_dev).  Staging lives in page-locked memory allocated once.
+// Compact (int32) layout; values beyond it make Rebuild fail with RQ_E_RANGE and
+// the caller falls back to BatchedDriver.
+class ResidentDriver {
+public:
+    struct Report {
+        uint32_t uploaded = 0;   // groups scattered to the device before the round
+        uint32_t changed = 0;    // groups gathered and applied after it
+        bool rebuilt = false;    // the whole image was flattened and uploaded (first step, or a log outgrew its slice)
+    };
+    ResidentDriver(std::vector<Group> groups, uint32_t slots, int device);
+    ~ResidentDriver();
+    ResidentDriver(const ResidentDriver &) = delete;
+    ResidentDriver &operator=(const ResidentDriver &) = delete;
+    void MarkDirty(uint32_t group);
+    int Step(Report *report = nullptr);      // an RQ_* code; flagged groups as in BatchedDriver::Step
+    const std::vector<GroupStatus> &Flagged() const { return flagged_; }
+    std::vector<Group> &Groups() { return groups_; }
+
+private:
+    struct Impl;
+    int Rebuild();
+    int FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms) const;
+    void ApplyRow(uint32_t g, const int32_t *row, uint64_t flags);
+    std::vector<Group> groups_;
+    uint32_t slots_;
+    int device_;
+    bool mixed_ = false;
+    std::vector<uint32_t> dirty_;
+    std::vector<uint8_t> dirty_mark_;
+    std::vector<GroupStatus> flagged_;
+    Impl *impl_ = nullptr;
 };
 
 }  // namespace raft

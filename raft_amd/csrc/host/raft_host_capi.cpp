@@ -2,6 +2,7 @@
 // tests can drive the C++ host the way Go tests inside `package raft` would
 // drive the Go host.  Not part of the product ABI (that is include/rq.h).
 #include <cstring>
+#include <ctime>
 #include <memory>
 
 #include "raft_host.hpp"
@@ -12,9 +13,11 @@ struct rh_cluster {
     uint32_t G = 0, n = 0;
     std::vector<Node *> nodes;  // group-major: nodes[g*n + p]
     std::unique_ptr<BatchedDriver> driver;
+    std::unique_ptr<ResidentDriver> resident;
     RoundBuffers last;
     ~rh_cluster() {
         driver.reset();
+        resident.reset();
         for (Node *x : nodes) delete x;
     }
 };
@@ -185,6 +188,128 @@ void rh_driver_apply(rh_cluster *c, const int32_t *commit_out, const int32_t *vo
 int rh_driver_step(rh_cluster *c, int device) { return c->driver->Step(device); }
 // 1 if the last successful step had to use the wide (int64) layout
 int rh_driver_last_step_wide(rh_cluster *c) { return c->driver->LastStepWide() ? 1 : 0; }
+
+// Groups the last rh_driver_step flagged (conditions that are Go panics in the
+// reference); fills up to cap entries, returns the total.
+uint32_t rh_driver_flagged(rh_cluster *c, uint32_t *groups, uint8_t *status, uint32_t cap) {
+    const std::vector<GroupStatus> &f = c->driver->Flagged();
+    for (uint32_t i = 0; i < f.size() && i < cap; i++) { groups[i] = f[i].group; status[i] = f[i].status; }
+    return (uint32_t)f.size();
+}
+// 1 if ThrowIfFlagged() raised the GoPanic of the first flagged group
+int rh_driver_throw_if_flagged(rh_cluster *c) {
+    try { c->driver->ThrowIfFlagged(); return 0; } catch (const GoPanic &) { return 1; }
+}
+
+// ---- resident driver over the same Node objects and group roles -------------
+// (created from the batched driver's current groups; roles set afterwards go
+// through rh_resident_roles)
+int rh_resident_new(rh_cluster *c, int device) {
+    c->resident.reset(new ResidentDriver(c->driver->Groups(), c->n, device));
+    return 0;
+}
+void rh_resident_roles(rh_cluster *c, uint32_t g, int leader_slot, int candidate_slot) {
+    Group &grp = c->resident->Groups()[g];
+    grp.Leader = leader_slot >= 0 ? at(c, g, (uint32_t)leader_slot) : nullptr;
+    grp.Candidate = candidate_slot >= 0 ? at(c, g, (uint32_t)candidate_slot) : nullptr;
+    c->resident->MarkDirty(g);
+}
+void rh_resident_get_roles(rh_cluster *c, uint32_t g, int *leader_slot, int *candidate_slot) {
+    Group &grp = c->resident->Groups()[g];
+    *leader_slot = *candidate_slot = -1;
+    for (uint32_t p = 0; p < c->n && p < grp.Members.size(); p++) {
+        if (grp.Members[p] == grp.Leader) *leader_slot = (int)p;
+        if (grp.Members[p] == grp.Candidate) *candidate_slot = (int)p;
+    }
+}
+void rh_resident_mark_dirty(rh_cluster *c, uint32_t g) { c->resident->MarkDirty(g); }
+// report[3]: groups uploaded, groups changed (downloaded and applied), 1 if the image was rebuilt
+int rh_resident_step(rh_cluster *c, uint32_t *report) {
+    ResidentDriver::Report r;
+    int rc = c->resident->Step(&r);
+    if (report) { report[0] = r.uploaded; report[1] = r.changed; report[2] = r.rebuilt ? 1 : 0; }
+    return rc;
+}
+uint32_t rh_resident_flagged(rh_cluster *c, uint32_t *groups, uint8_t *status, uint32_t cap) {
+    const std::vector<GroupStatus> &f = c->resident->Flagged();
+    for (uint32_t i = 0; i < f.size() && i < cap; i++) { groups[i] = f[i].group; status[i] = f[i].status; }
+    return (uint32_t)f.size();
+}
+
+// Timing hook for the resident driver at sizes a Python loop cannot seed: G groups
+// of n nodes, every group led by its slot 0 (log of 1..16 entries, one term),
+// image resident on `device`.  Each of `steps` steps the host applies one client
+// entry to `dirty` randomly chosen groups -- the leader's log grows by one entry
+// and a majority's matchIndex moves to it -- marks them dirty and calls Step.
+// out[0] = first Step (flatten + upload of the whole image) in ms, out[1] = mean
+// microseconds per later Step, out[2] / out[3] = mean groups uploaded / applied
+// per step, out[4] = rebuilds among the later steps, out[5] = one
+// BatchedDriver::Step on the same objects in ms (0 if skipped).
+int rh_resident_bench(uint32_t G, uint32_t n, uint32_t dirty, uint32_t steps, int device, int with_batched,
+                      double *out) {
+    std::vector<Node *> nodes;
+    nodes.reserve((size_t)G * n);
+    std::vector<Group> groups(G);
+    uint64_t rng = 0x5EED0001ull;
+    auto next = [&rng]() { rng = rng * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(rng >> 33); };
+    for (uint32_t g = 0; g < G; g++) {
+        std::vector<Node *> peers;
+        for (uint32_t p = 0; p < n; p++) {
+            Node *x = NewNode((int64_t)p, peers, nullptr);
+            peers.push_back(x);
+            nodes.push_back(x);
+        }
+        const uint32_t len = 1 + next() % 16;
+        std::vector<int64_t> terms(len, 1);
+        for (uint32_t p = 0; p < n; p++) {
+            peers[p]->SeedForTest(1, -1, p == 0 ? Leader : Follower, 0);
+            peers[p]->SeedLogForTest(p == 0 ? terms : std::vector<int64_t>(1, 1));
+        }
+        peers[0]->BecomeLeader();
+        std::vector<int64_t> &m = peers[0]->MatchIndexForTest();
+        for (uint32_t p = 0; p < n; p++) m[p] = next() % len;
+        groups[g].Members = peers;
+        groups[g].Leader = peers[0];
+    }
+    auto now = []() { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; };
+    int rc = 0;
+    {
+        ResidentDriver rd(groups, n, device);
+        double t0 = now();
+        rc = rd.Step();
+        out[0] = (now() - t0) * 1e3;
+        double up = 0, ch = 0, rebuilds = 0, total = 0;
+        for (uint32_t s = 0; s < steps && rc == 0; s++) {
+            for (uint32_t i = 0; i < dirty; i++) {
+                const uint32_t g = next() % G;
+                Node *l = rd.Groups()[g].Leader;
+                const int64_t idx = l->Inspect().logLen;
+                std::vector<Entry> one(1, Entry{"", idx, 1});
+                l->AppendForTest(one);
+                std::vector<int64_t> &m = l->MatchIndexForTest();
+                for (uint32_t p = 0; p < (n / 2) + 1; p++) m[p] = idx;
+                rd.MarkDirty(g);
+            }
+            ResidentDriver::Report r;
+            t0 = now();
+            rc = rd.Step(&r);
+            total += now() - t0;
+            up += r.uploaded; ch += r.changed; rebuilds += r.rebuilt ? 1 : 0;
+        }
+        out[1] = steps ? total / steps * 1e6 : 0;
+        out[2] = steps ? up / steps : 0; out[3] = steps ? ch / steps : 0; out[4] = rebuilds;
+    }
+    out[5] = 0;
+    if (rc == 0 && with_batched) {
+        BatchedDriver bd(groups, n);
+        rc = bd.Step(device);                     // creates the engine, first touch
+        double t0 = now();
+        if (rc == 0) rc = bd.Step(device);
+        out[5] = (now() - t0) * 1e3;
+    }
+    for (Node *x : nodes) delete x;
+    return rc;
+}
 
 // Wide-layout Flatten: returns the driver code and the number of log terms; copies nothing
 // when an output pointer is null.  Planes are [n][G] int64.

@@ -1,0 +1,322 @@
+// raft_host_resident.cpp -- raft::ResidentDriver, see raft_host.hpp.
+#include <climits>
+#include <cstring>
+
+#include "../../../include/rq.h"
+#include "raft_host.hpp"
+
+namespace raft {
+
+namespace {
+
+constexpr uint32_t kMaxRowsPerTransfer = 1u << 18;   // staging rows; more dirty groups than this: full rebuild
+
+bool narrow32(int64_t v, int32_t &out) {
+    if (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX) return false;   // INT32_MIN is the empty-log marker
+    out = (int32_t)v;
+    return true;
+}
+
+// room a group's arena slice keeps for its log to grow before the image is rebuilt
+uint32_t slice_capacity(size_t len) { return (uint32_t)(len + (len / 4 > 4 ? len / 4 : 4)); }
+
+}  // namespace
+
+struct ResidentDriver::Impl {
+    rq_engine *e = nullptr;
+    rq_plan *plan = nullptr;
+    rq_round_desc desc;
+    uint32_t G = 0, n = 0, row_cap = 0;
+    uint64_t term_cap = 0;              // log terms one scatter can carry
+    std::vector<void *> device_allocs, host_allocs;
+    // the arena as the host manages it: every group's slice (offset, capacity), free space from `tail` on
+    std::vector<uint32_t> off, cap;
+    uint64_t tail = 0, arena_entries = 0;
+    // staging: one block going up (group ids, term offsets, rows, terms packed back to back for the
+    // rows actually sent), one coming down (flags, rows); page-locked mirrors of the same size
+    char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
+    uint64_t *h_cbits = nullptr;
+
+    int dalloc(uint64_t bytes, void **out) {
+        int rc = rq_device_alloc(e, bytes ? bytes : 4, RQ_MEM_DEFAULT, out);
+        if (rc == RQ_OK) device_allocs.push_back(*out);
+        return rc;
+    }
+    template <typename P> int halloc(uint64_t bytes, P **out) {
+        void *p = nullptr;
+        int rc = rq_host_alloc(e, bytes ? bytes : 4, &p);
+        if (rc == RQ_OK) host_allocs.push_back(p);
+        *out = static_cast<P *>(p);
+        return rc;
+    }
+    void release() {
+        if (plan) rq_plan_destroy(plan);
+        plan = nullptr;
+        for (void *p : device_allocs) rq_device_free(e, p);
+        for (void *p : host_allocs) rq_host_free(e, p);
+        device_allocs.clear(); host_allocs.clear();
+    }
+};
+
+ResidentDriver::ResidentDriver(std::vector<Group> groups, uint32_t slots, int device)
+    : groups_(std::move(groups)), slots_(slots), device_(device), dirty_mark_(groups_.size(), 0) {}
+
+ResidentDriver::~ResidentDriver() {
+    if (impl_) {
+        impl_->release();
+        if (impl_->e) rq_engine_destroy(impl_->e);
+        delete impl_;
+    }
+}
+
+void ResidentDriver::MarkDirty(uint32_t group) {
+    if (group < dirty_mark_.size() && !dirty_mark_[group]) {
+        dirty_mark_[group] = 1;
+        dirty_.push_back(group);
+    }
+}
+
+// One group as a scatter row (layout of rq_groups_scatter_dev) plus its leader's
+// log terms.  A group without a leader gets commit = INT32_MAX (N > commit is
+// never true); a group without a candidate gets a term below every voter's.
+int ResidentDriver::FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms) const {
+    const Group &grp = groups_[g];
+    const uint32_t n = slots_, k = (uint32_t)grp.Members.size();
+    if (k < 1 || k > n || n > RQ_MAX_SLOTS) return RQ_E_ARG;
+    int32_t *match = row, *vt = row + n, *vf = row + 2 * n, *ll = row + 3 * n, *tail = row + 4 * n;
+    for (uint32_t p = 0; p < n; p++) { match[p] = 0; vt[p] = 0; vf[p] = -1; ll[p] = RQ_LOG_EMPTY; }
+    tail[0] = INT32_MAX; tail[1] = 0; tail[2] = INT32_MIN + 1; tail[3] = -1; tail[4] = 0;
+    const uint32_t mask = (1u << k) - 1u;
+    tail[5] = (int32_t)(mask | (mask << 16));
+    terms.clear();
+    if (const Node *l = grp.Leader) {
+        if (!narrow32(l->commitIndex, tail[0]) || !narrow32(l->currentTerm, tail[1])) return RQ_E_RANGE;
+        for (uint32_t p = 0; p < k && p < l->matchIndex.size(); p++)
+            if (!narrow32(l->matchIndex[p], match[p])) return RQ_E_RANGE;
+        terms.resize(l->log.size());
+        for (size_t i = 0; i < l->log.size(); i++)
+            if (!narrow32(l->log[i].TermNum, terms[i])) return RQ_E_RANGE;
+    }
+    if (const Node *c = grp.Candidate) {
+        if (!narrow32(c->currentTerm, tail[2]) || !narrow32(c->id, tail[3])) return RQ_E_RANGE;
+    }
+    for (uint32_t p = 0; p < k; p++) {
+        const Node *m = grp.Members[p];
+        if (!narrow32(m->currentTerm, vt[p]) || !narrow32(m->votedFor, vf[p])) return RQ_E_RANGE;
+        if (!m->log.empty() && !narrow32(m->log.back().TermNum, ll[p])) return RQ_E_RANGE;
+    }
+    return RQ_OK;
+}
+
+// The whole image: every group flattened, arena slices sized with room to grow,
+// device buffers, staging and the prepared launch made afresh.
+int ResidentDriver::Rebuild() {
+    const uint32_t G = (uint32_t)groups_.size(), n = slots_;
+    if (G == 0 || n < 1 || n > RQ_MAX_SLOTS) return RQ_E_ARG;
+    if (!impl_) impl_ = new Impl();
+    Impl &I = *impl_;
+    if (!I.e) {
+        int rc = rq_engine_create(device_, 64, 1, 64, &I.e);   // the engine only binds the device here
+        if (rc != RQ_OK) { I.e = nullptr; return rc; }
+    }
+    I.release();
+    I.G = G; I.n = n;
+    const size_t ld = G, plane = (size_t)n * ld, words = 4 * (size_t)n + 7;
+    std::vector<int32_t> match(plane), vt(plane), vf(plane), ll(plane), commit(G), lterm(G), cterm(G), cid(G), arena;
+    std::vector<uint32_t> len(G);
+    std::vector<uint16_t> om(G), nm(G);
+    I.off.assign((size_t)G + 1, 0);
+    I.cap.assign(G, 0);
+    std::vector<int32_t> row(words), terms;
+    mixed_ = false;
+    for (uint32_t g = 0; g < G; g++) {
+        int rc = FlattenRow(g, row.data(), terms);
+        if (rc != RQ_OK) return rc;
+        for (uint32_t p = 0; p < n; p++) {
+            match[p * ld + g] = row[p]; vt[p * ld + g] = row[n + p];
+            vf[p * ld + g] = row[2 * n + p]; ll[p * ld + g] = row[3 * n + p];
+        }
+        const int32_t *tail = row.data() + 4 * n;
+        commit[g] = tail[0]; lterm[g] = tail[1]; cterm[g] = tail[2]; cid[g] = tail[3];
+        om[g] = (uint16_t)((uint32_t)tail[5] & 0xFFFFu); nm[g] = (uint16_t)((uint32_t)tail[5] >> 16);
+        if (groups_[g].Members.size() != n) mixed_ = true;
+        len[g] = (uint32_t)terms.size();
+        I.cap[g] = slice_capacity(terms.size());
+        const uint64_t next = (uint64_t)I.off[g] + I.cap[g];
+        if (next > 0xFFFFFFFFull) return RQ_E_RANGE;
+        I.off[g + 1] = (uint32_t)next;
+        arena.resize(next, 0);
+        std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * 4);
+    }
+    // free space behind the slices: logs that outgrow their slice move there
+    I.tail = arena.size();
+    I.arena_entries = arena.size() + arena.size() / 2 + (1u << 16);
+    if (I.arena_entries > 0xFFFFFFFFull) I.arena_entries = 0xFFFFFFFFull;
+    arena.resize(I.arena_entries, 0);
+
+    rq_round_desc &d = I.desc;
+    std::memset(&d, 0, sizeof d);
+    d.struct_size = sizeof d; d.layout = RQ_LAYOUT_I32; d.what = RQ_ROUND_COMMIT | RQ_ROUND_VOTE;
+    d.G = G; d.n = n; d.ld = (uint32_t)ld; d.log_terms = arena.size();
+    void *p = nullptr;
+    auto upload = [&](const void *src, uint64_t bytes, const void **field) {
+        int rc = I.dalloc(bytes, &p);
+        if (rc == RQ_OK) rc = rq_copy_to_device(I.e, p, src, bytes);
+        *field = p;
+        return rc;
+    };
+#define RH_TRY(x) do { int rh_rc_ = (x); if (rh_rc_ != RQ_OK) return rh_rc_; } while (0)
+    RH_TRY(upload(match.data(), plane * 4, &d.match));
+    RH_TRY(upload(vt.data(), plane * 4, &d.voter_term));
+    RH_TRY(upload(vf.data(), plane * 4, &d.voted_for));
+    RH_TRY(upload(ll.data(), plane * 4, &d.voter_last_log_term));
+    RH_TRY(upload(commit.data(), (uint64_t)G * 4, &d.commit));
+    RH_TRY(upload(lterm.data(), (uint64_t)G * 4, &d.leader_term));
+    RH_TRY(upload(cterm.data(), (uint64_t)G * 4, &d.cand_term));
+    RH_TRY(upload(cid.data(), (uint64_t)G * 4, &d.cand_id));
+    RH_TRY(upload(I.off.data(), ((uint64_t)G + 1) * 4, (const void **)&d.log_off));
+    RH_TRY(upload(len.data(), (uint64_t)G * 4, (const void **)&d.log_len));
+    RH_TRY(upload(arena.data(), (uint64_t)arena.size() * 4, &d.log_term));
+    if (mixed_) {
+        RH_TRY(upload(om.data(), (uint64_t)G * 2, (const void **)&d.old_mask));
+        RH_TRY(upload(nm.data(), (uint64_t)G * 2, (const void **)&d.new_mask));
+    }
+    // state is updated in place between rounds, as the host applies it to its Nodes
+    d.commit_out = const_cast<void *>(d.commit);
+    d.voter_term_out = const_cast<void *>(d.voter_term);
+    RH_TRY(I.dalloc((uint64_t)G * 2, (void **)&d.grant_mask));
+    RH_TRY(I.dalloc((uint64_t)G * 2, (void **)&d.stepdown_mask));
+    RH_TRY(I.dalloc(G, (void **)&d.elected));
+    RH_TRY(I.dalloc((uint64_t)G * 4, &d.max_term));
+    RH_TRY(I.dalloc(G, (void **)&d.status_out));
+    const uint64_t bit_words = ((uint64_t)G + 63) / 64;
+    RH_TRY(I.dalloc(bit_words * 8, (void **)&d.changed_bits));
+    RH_TRY(rq_plan_round(I.e, &d, &I.plan));
+
+    I.row_cap = G < kMaxRowsPerTransfer ? G : kMaxRowsPerTransfer;
+    const uint64_t nrows = I.row_cap;
+    I.term_cap = 64ull * nrows < I.arena_entries ? 64ull * nrows : I.arena_entries;
+    const uint64_t in_bytes = (nrows * (words + 2) + 1 + I.term_cap) * 4, out_bytes = nrows * (8 + (n + 2) * 4);
+    RH_TRY(I.dalloc(in_bytes, (void **)&I.d_in));    RH_TRY(I.halloc(in_bytes, &I.h_in));
+    RH_TRY(I.dalloc(out_bytes, (void **)&I.d_out));  RH_TRY(I.halloc(out_bytes, &I.h_out));
+    RH_TRY(I.halloc(bit_words * 8, &I.h_cbits));
+    for (uint32_t g : dirty_) dirty_mark_[g] = 0;
+    dirty_.clear();
+    return RQ_OK;
+}
+
+// One gathered row back into the objects: voters' terms and roles
+// (raft.go:219-221), the leader's commitIndex, BecomeLeader for a winner.
+void ResidentDriver::ApplyRow(uint32_t g, const int32_t *row, uint64_t flags) {
+    Group &grp = groups_[g];
+    const uint32_t stepdown = (uint32_t)(flags >> 16) & 0xFFFFu;
+    const bool elected = ((flags >> 32) & 0xFFu) != 0;
+    const uint8_t status = (uint8_t)((flags >> 40) & 0xFFu);
+    Node *leader_before = grp.Leader;
+    if (grp.Candidate) {
+        for (uint32_t p = 0; p < slots_ && p < grp.Members.size(); p++) {
+            Node *m = grp.Members[p];
+            m->currentTerm = row[2 + p];
+            if ((stepdown >> p) & 1u) m->nodeType = Follower;
+        }
+        if (elected) {
+            grp.Candidate->BecomeLeader();
+            grp.Leader = grp.Candidate;
+            grp.Candidate = nullptr;
+            MarkDirty(g);                 // new leader arrays, no candidate: the row goes up again
+        }
+    }
+    if (leader_before) leader_before->commitIndex = row[0];
+    if (status) flagged_.push_back(GroupStatus{g, status});
+}
+
+int ResidentDriver::Step(Report *report) {
+    Report rep;
+    flagged_.clear();
+    bool need_rebuild = impl_ == nullptr || impl_->plan == nullptr;
+    if (!need_rebuild && dirty_.size() > impl_->row_cap) need_rebuild = true;
+    if (!need_rebuild && !dirty_.empty()) {
+        Impl &I = *impl_;
+        const uint32_t n = I.n, r = (uint32_t)dirty_.size();
+        const size_t words = 4 * (size_t)n + 7;
+        // block going up, packed for r rows: group ids | term offsets (r + 1) | rows | terms
+        uint32_t *gids = (uint32_t *)I.h_in, *roff = gids + r;
+        int32_t *rows = (int32_t *)(roff + r + 1), *rterms = rows + (size_t)r * words;
+        std::vector<int32_t> terms;
+        uint64_t used = 0;
+        for (uint32_t i = 0; i < r && !need_rebuild; i++) {
+            const uint32_t g = dirty_[i];
+            int32_t *row = rows + (size_t)i * words;
+            RH_TRY(FlattenRow(g, row, terms));
+            if (!mixed_ && groups_[g].Members.size() != n) { need_rebuild = true; break; }
+            if (terms.size() > I.cap[g]) {
+                // the log outgrew its slice: it moves to free space with twice the room;
+                // when that runs out everything is laid out afresh
+                const uint64_t want = 2 * (uint64_t)terms.size() + 4;
+                if (I.tail + want > I.arena_entries) { need_rebuild = true; break; }
+                I.off[g] = (uint32_t)I.tail;
+                I.cap[g] = (uint32_t)want;
+                I.tail += want;
+            }
+            if (used + terms.size() > I.term_cap) { need_rebuild = true; break; }
+            row[4 * n + 6] = (int32_t)I.off[g];
+            gids[i] = g;
+            roff[i] = (uint32_t)used;
+            std::memcpy(rterms + used, terms.data(), terms.size() * 4);
+            used += terms.size();
+        }
+        if (!need_rebuild) {
+            roff[r] = (uint32_t)used;
+            const uint64_t bytes = ((uint64_t)r * (words + 2) + 1 + used) * 4;
+            RH_TRY(rq_copy_to_device(I.e, I.d_in, I.h_in, bytes));
+            const char *d = I.d_in;
+            RH_TRY(rq_groups_scatter_dev(I.e, nullptr, &I.desc, r, (const uint32_t *)d,
+                                         d + ((const char *)rows - I.h_in), (const uint32_t *)(d + ((const char *)roff - I.h_in)),
+                                         d + ((const char *)rterms - I.h_in), nullptr));
+            rep.uploaded = r;
+            for (uint32_t g : dirty_) dirty_mark_[g] = 0;
+            dirty_.clear();
+        }
+    }
+    if (need_rebuild) {
+        RH_TRY(Rebuild());
+        rep.rebuilt = true;
+        rep.uploaded = (uint32_t)groups_.size();
+    }
+    Impl &I = *impl_;
+    RH_TRY(rq_plan_launch(I.plan, nullptr));
+    const uint64_t bit_words = ((uint64_t)I.G + 63) / 64;
+    RH_TRY(rq_copy_from_device(I.e, I.h_cbits, I.desc.changed_bits, bit_words * 8));   // ordered after the round
+    // the groups the round changed or flagged, in chunks of the staging size; block
+    // coming down, packed for r rows: flags (r x 8 bytes) | rows
+    uint32_t r = 0;
+    uint32_t *gids = (uint32_t *)I.h_in;
+    auto flush = [&]() -> int {
+        if (r == 0) return RQ_OK;
+        RH_TRY(rq_copy_to_device(I.e, I.d_in, I.h_in, (uint64_t)r * 4));
+        RH_TRY(rq_groups_gather_dev(I.e, nullptr, &I.desc, r, (const uint32_t *)I.d_in, I.d_out + (uint64_t)r * 8,
+                                    (uint64_t *)I.d_out));
+        RH_TRY(rq_copy_from_device(I.e, I.h_out, I.d_out, (uint64_t)r * (8 + (I.n + 2) * 4)));
+        const uint64_t *flags = (const uint64_t *)I.h_out;
+        const int32_t *orows = (const int32_t *)(I.h_out + (uint64_t)r * 8);
+        for (uint32_t i = 0; i < r; i++) ApplyRow(gids[i], orows + (size_t)i * (I.n + 2), flags[i]);
+        rep.changed += r;
+        r = 0;
+        return RQ_OK;
+    };
+    for (uint64_t w = 0; w < bit_words; w++) {
+        uint64_t bits = I.h_cbits[w];
+        while (bits) {
+            const uint32_t g = (uint32_t)(w * 64 + (uint64_t)__builtin_ctzll(bits));
+            bits &= bits - 1;
+            gids[r++] = g;
+            if (r == I.row_cap) RH_TRY(flush());
+        }
+    }
+    RH_TRY(flush());
+    if (report) *report = rep;
+    return RQ_OK;
+}
+#undef RH_TRY
+
+}  // namespace raft

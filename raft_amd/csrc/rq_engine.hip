@@ -318,6 +318,7 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     a.match = (const T *)d.match; a.commit = (const T *)d.commit; a.leader_term = (const T *)d.leader_term;
     a.log_off = d.log_off; a.log_term = d.log_term;
     a.log_base = (const T *)d.log_base; a.log_term_base = (const T *)d.log_term_base;
+    a.log_len = d.log_len;
     a.log_terms = d.log_terms;
     a.log_term_bits = d.log_term_bits ? d.log_term_bits : (uint32_t)(8 * sizeof(T));
     a.voter_term = (const T *)d.voter_term; a.voted_for = (const T *)d.voted_for;
@@ -326,6 +327,7 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     a.commit_out = (T *)d.commit_out; a.voter_term_out = (T *)d.voter_term_out;
     a.grant_mask = d.grant_mask; a.stepdown_mask = d.stepdown_mask; a.elected = d.elected;
     a.max_term = (T *)d.max_term; a.status_out = d.status_out; a.elected_bits = d.elected_bits;
+    a.changed_bits = d.changed_bits;
     a.commit_lo16 = (uint16_t *)d.commit_summary; a.summary_base = (const T *)d.summary_base;
     a.summary_escapes = d.summary_escapes; a.summary_bits = sb;
     return RQ_OK;
@@ -907,6 +909,35 @@ int rq_plan_round(rq_engine *e, const rq_round_desc *d, rq_plan **out) {
 int rq_plan_launch(rq_plan *p, void *stream) {
     if (!p) return RQ_E_ARG;
     return launch_plan(*p, stream);
+}
+
+int rq_groups_scatter_dev(rq_engine *e, void *stream, const rq_round_desc *d, uint32_t count,
+                          const uint32_t *gids, const void *rows, const uint32_t *row_log_off,
+                          const void *row_log_terms, uint8_t *row_status) {
+    rq_plan p;
+    RQ_TRY(plan_from_desc(e, d, p));
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipError_t err = p.wide
+        ? rq_launch_groups_scatter(p.args64, p.n, count, gids, (const int64_t *)rows, row_log_off,
+                                   (const int64_t *)row_log_terms, row_status, (hipStream_t)stream)
+        : rq_launch_groups_scatter(p.args, p.n, count, gids, (const int32_t *)rows, row_log_off,
+                                   (const int32_t *)row_log_terms, row_status, (hipStream_t)stream);
+    if (err == hipErrorInvalidValue) return RQ_E_ARG;
+    RQ_HIP(e, err);
+    return RQ_OK;
+}
+
+int rq_groups_gather_dev(rq_engine *e, void *stream, const rq_round_desc *d, uint32_t count,
+                         const uint32_t *gids, void *rows_out, uint64_t *flags_out) {
+    rq_plan p;
+    RQ_TRY(plan_from_desc(e, d, p));
+    RQ_HIP(e, hipSetDevice(e->device));
+    hipError_t err = p.wide
+        ? rq_launch_groups_gather(p.args64, p.n, count, gids, (int64_t *)rows_out, flags_out, (hipStream_t)stream)
+        : rq_launch_groups_gather(p.args, p.n, count, gids, (int32_t *)rows_out, flags_out, (hipStream_t)stream);
+    if (err == hipErrorInvalidValue) return RQ_E_ARG;
+    RQ_HIP(e, err);
+    return RQ_OK;
 }
 
 int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d) {

@@ -21,6 +21,7 @@ struct rq_round_args_t {
     const void *log_term;     // arena of log_term_bits-wide entries
     const T *log_base;        // may be null (0): arena slot 0 of group g holds log[log_base[g]]
     const T *log_term_base;   // may be null (0): added to every arena entry of group g
+    const uint32_t *log_len;  // may be null: group g's log is the first log_len[g] entries of its slice
     uint64_t log_terms;       // entries in the arena: no lookup goes at or beyond it
     uint32_t log_term_bits;   // 8, 16 (unsigned entries), 32 (signed) or 8 * sizeof(T)
     // vote side (RequestVoteRPC inputs, raft.go:181-210)
@@ -41,6 +42,7 @@ struct rq_round_args_t {
     T *max_term;
     uint8_t  *status_out;    // may be null
     uint64_t *elected_bits;  // may be null
+    uint64_t *changed_bits;  // may be null: 1 bit per group, set when the round changed or flagged anything
     // narrow summary for the sharded exchange (all may be null): per group
     // commit'[g] - summary_base[g] in summary_bits (16, 8 or 4) bits, all ones = "does
     // not fit".  16: uint16 per group; 8: uint8 per group; 4: 16 groups per 64-bit
@@ -117,6 +119,28 @@ hipError_t rq_launch_follower_clamp(uint64_t count, const int64_t *leader_commit
                                     const int64_t *commit,
                                     const int64_t *last_new_index,
                                     int64_t *commit_out, hipStream_t stream);
+
+// Incremental host <-> device exchange of single groups for a host that keeps the
+// state of a round_args set resident.  Scatter: row r overwrites group gids[r]:
+// rows[r] = { match[n], voter_term[n], voted_for[n], last_log_term[n], commit,
+// leader_term, cand_term, cand_id, log_base } as T words; the group's log terms are
+// row_terms[row_off[r] .. row_off[r+1]) (T words), written into its arena slice in
+// the arena's entry width after subtracting log_term_base[g]; log_len[g] is set.
+// row_status[r] (may be null): 1 = the terms do not fit the slice's capacity
+// (nothing of the log written), 2 = a term does not fit the entry width, 4 = gid
+// out of range (row ignored).  Gather: rows_out[r] = { commit, max_term,
+// voter_term[n] } as T words, flags_out[r] = grant | stepdown << 16 | elected << 32
+// | status << 40.
+hipError_t rq_launch_groups_scatter(const rq_round_args &a, uint32_t n, uint32_t count, const uint32_t *gids,
+                                    const int32_t *rows, const uint32_t *row_off, const int32_t *row_terms,
+                                    uint8_t *row_status, hipStream_t stream);
+hipError_t rq_launch_groups_scatter(const rq_round64_args &a, uint32_t n, uint32_t count, const uint32_t *gids,
+                                    const int64_t *rows, const uint32_t *row_off, const int64_t *row_terms,
+                                    uint8_t *row_status, hipStream_t stream);
+hipError_t rq_launch_groups_gather(const rq_round_args &a, uint32_t n, uint32_t count, const uint32_t *gids,
+                                   int32_t *rows_out, uint64_t *flags_out, hipStream_t stream);
+hipError_t rq_launch_groups_gather(const rq_round64_args &a, uint32_t n, uint32_t count, const uint32_t *gids,
+                                   int64_t *rows_out, uint64_t *flags_out, hipStream_t stream);
 
 // Summary consumer of a sharded deployment: adds the gathered narrow commit
 // summaries (advance coding) of `ranks` ranks to this rank's replica of every

@@ -3,6 +3,7 @@
 // consistency batch and the follower commit clamp (rq_append_impl.h)
 // instantiated for int32_t.
 #include "rq_append_impl.h"
+#include "rq_groups_impl.h"
 
 hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, int what,
                            int variant, hipStream_t stream) {
@@ -17,6 +18,17 @@ hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit
                                     const int32_t *commit, const int32_t *last_new_index,
                                     int32_t *commit_out, hipStream_t stream) {
     return launch_follower_clamp_impl<int32_t>(count, leader_commit, commit, last_new_index, commit_out, stream);
+}
+
+hipError_t rq_launch_groups_scatter(const rq_round_args &a, uint32_t n, uint32_t count, const uint32_t *gids,
+                                    const int32_t *rows, const uint32_t *row_off, const int32_t *row_terms,
+                                    uint8_t *row_status, hipStream_t stream) {
+    return launch_groups_scatter_impl<int32_t>(a, n, count, gids, rows, row_off, row_terms, row_status, stream);
+}
+
+hipError_t rq_launch_groups_gather(const rq_round_args &a, uint32_t n, uint32_t count, const uint32_t *gids,
+                                   int32_t *rows_out, uint64_t *flags_out, hipStream_t stream) {
+    return launch_groups_gather_impl<int32_t>(a, n, count, gids, rows_out, flags_out, stream);
 }
 
 // ---------------------------------------------------------------------------

@@ -260,6 +260,12 @@ __device__ __forceinline__ T load_term(const void *arena, uint32_t bits, size_t 
 __device__ __forceinline__ bool slice_ok(uint32_t beg, uint32_t end, uint64_t total) {
     return beg <= end && (uint64_t)end <= total;
 }
+// With a length plane group g's log is the `len` entries from `beg` on, wherever
+// that lies in the arena (a resident arena whose slices have room to grow and
+// move when they run out of it): usable when it ends inside the arena.
+__device__ __forceinline__ bool span_ok(uint32_t beg, uint32_t len, uint64_t total) {
+    return (uint64_t)beg + (uint64_t)len <= total;
+}
 
 // Narrow commit summary: commit' as an offset from a per-group base in `bits`
 // (16, 8 or 4) bits, the all-ones value meaning "does not fit, fetch the full
@@ -329,6 +335,7 @@ struct round_fields {
     uint32_t elected;   // bit k: group g0+k elected
     uint32_t nibbles;   // 4 bits per group: 4-bit commit summary
     uint32_t escapes;   // groups of this thread whose summary offset did not fit
+    uint32_t changed;   // bit k: the round moved commitIndex, stepped a voter down, elected or flagged group g0+k
 };
 
 // Slot of log[N] inside the group's arena slice, as an unsigned number: with a
@@ -353,9 +360,9 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     const size_t ld = a.ld;
 
     T mt[N][V], cm[V], lt[V], lb[V], tb[V];
-    int32_t off[V + 1];
+    int32_t off[V + 1], ln[V];
 #pragma unroll
-    for (int k = 0; k < V; k++) { lb[k] = 0; tb[k] = 0; }
+    for (int k = 0; k < V; k++) { lb[k] = 0; tb[k] = 0; ln[k] = 0; }
     T vt[N][V], vf[N][V], ll[N][V], ct[V], ci[V];
     uint32_t st[V];
 #pragma unroll
@@ -369,6 +376,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
         ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
         if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
         if (a.log_term_base) ld_i32<V, NTL, FULL>(a.log_term_base + g0, valid, tb);
+        if (a.log_len) ld_i32<V, NTL, FULL>(reinterpret_cast<const int32_t *>(a.log_len) + g0, valid, ln);
         const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
         int32_t o[V];
         ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -401,10 +409,11 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             for (int p = 0; p < N; p++) s[p] = mt[p][k];
             nq[k] = quorum_index<N>(s);
             const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
-            const bool csr = slice_ok(beg, end, a.log_terms);
+            const bool csr = a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms);
+            const uint32_t len = a.log_len ? (uint32_t)ln[k] : end - beg;
             const U wi = window_slot(nq[k], lb[k]);
             adv[k] = (k < valid) && nq[k] > cm[k];
-            inb[k] = csr && wi < (U)(end - beg);
+            inb[k] = csr && wi < (U)len;
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
             gt[k] = 0;
             if (adv[k] && inb[k])
@@ -413,7 +422,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     }
 
     // ---- vote: per-slot predicate, tally ----
-    uint32_t el_field = 0, nib_field = 0, esc_field = 0;
+    uint32_t el_field = 0, nib_field = 0, esc_field = 0, ch_field = 0;
     if constexpr (DO_VOTE) {
         uint32_t gm[V], sm[V], el[V];
         T mx[V];
@@ -437,6 +446,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
         for (int k = 0; k < V; k++) {
             el[k] = (2 * __popc(gm[k]) > N) && (mx[k] == ct[k]);
             if (k < valid) el_field |= el[k] << k;
+            if (k < valid) ch_field |= (uint32_t)(el[k] != 0 || sm[k] != 0) << k;
         }
         st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
         st_u16<V, NTS, FULL>(a.stepdown_mask + g0, valid, sm);
@@ -451,18 +461,22 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
         for (int k = 0; k < V; k++) {
             co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
+            if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
         st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
         if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm, esc_field);
     }
     if (a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return round_fields{el_field, nib_field, esc_field};
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        if (k < valid) ch_field |= (uint32_t)(st[k] != 0) << k;
+    return round_fields{el_field, nib_field, esc_field, ch_field};
 }
 
 template <int N, int V, int WHAT, bool NT, bool NTG, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
-    round_fields f{0, 0, 0};
+    round_fields f{0, 0, 0, 0};
     if (g0 + V <= a.G)
         f = round_fixed_body<N, V, WHAT, NT, NTG, true>(a, (uint32_t)g0, V);
     else if (g0 < a.G)
@@ -470,6 +484,7 @@ __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
         if (a.elected_bits) pack_elected<V>(f.elected, g0, a.G, a.elected_bits);
     }
+    if (a.changed_bits) pack_elected<V>(f.changed, g0, a.G, a.changed_bits);
     if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
         if (a.commit_lo16 && a.summary_bits == 4)
             pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));
@@ -570,7 +585,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
     // loads are all issued before any of them is consumed, and chunk 0 is issued
     // before the commit side's sort so that it is in flight behind it.
     constexpr int kChunk = 8;
-    uint32_t el_field = 0, nib_field = 0, esc_field = 0;
+    uint32_t el_field = 0, nib_field = 0, esc_field = 0, ch_field = 0;
     T ct[V], ci[V], mx[V];
     uint32_t gm[V], sm[V];
     T cvt[kChunk][V], cvf[kChunk][V], cll[kChunk][V];
@@ -645,14 +660,16 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             }
         }
         T lb[V], tb[V];
+        int32_t ln[V];
 #pragma unroll
-        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; tb[k] = 0; }
+        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; tb[k] = 0; ln[k] = 0; }
         off[V] = 0;
         if (in_range) {
             ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
             ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
             if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
             if (a.log_term_base) ld_i32<V, NTL, FULL>(a.log_term_base + g0, valid, tb);
+            if (a.log_len) ld_i32<V, NTL, FULL>(reinterpret_cast<const int32_t *>(a.log_len) + g0, valid, ln);
             const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
             int32_t o[V];
             ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -679,10 +696,11 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             }
             nq[k] = tmin(no, nn);
             const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
-            const bool csr = slice_ok(beg, end, a.log_terms);
+            const bool csr = a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms);
+            const uint32_t len = a.log_len ? (uint32_t)ln[k] : end - beg;
             const U wi = window_slot(nq[k], lb[k]);
             adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
-            inb[k] = csr && wi < (U)(end - beg);
+            inb[k] = csr && wi < (U)len;
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
             gt[k] = 0;
             if (adv[k] && inb[k])
@@ -705,6 +723,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             const bool maj_new = 2 * __popc(gm[k] & nm[k]) > __popc(nm[k]);
             el[k] = maj_old && maj_new && (mx[k] == ct[k]) && mem[k] != 0;
             if (k < valid) el_field |= el[k] << k;
+            if (k < valid) ch_field |= (uint32_t)(el[k] != 0 || sm[k] != 0) << k;
         }
         if (in_range) {
             st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
@@ -720,6 +739,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         for (int k = 0; k < V; k++) {
             co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
+            if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
         if (in_range) {
             st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
@@ -727,7 +747,10 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         }
     }
     if (in_range && a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
-    return round_fields{el_field, nib_field, esc_field};
+#pragma unroll
+    for (int k = 0; k < V; k++)
+        if (k < valid) ch_field |= (uint32_t)(st[k] != 0) << k;
+    return round_fields{el_field, nib_field, esc_field, ch_field};
 }
 
 template <int MMAX, int V, int WHAT, bool NT, bool NTG, typename T>
@@ -745,6 +768,7 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
         if (a.elected_bits) pack_elected<V>(f.elected, g0, a.G, a.elected_bits);
     }
+    if (a.changed_bits) pack_elected<V>(f.changed, g0, a.G, a.changed_bits);
     if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
         if (a.commit_lo16 && a.summary_bits == 4)
             pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));

@@ -256,6 +256,7 @@ class DeviceEngine:
             d.match, d.commit, d.leader_term = p(t["match"]), p(t["commit"]), p(t["leader_term"])
             d.log_off, d.log_term = p(t["log_off"]), p(t["log_term"])
             d.log_base, d.log_term_base = p(t.get("log_base")), p(t.get("log_term_base"))
+            d.log_len = p(t.get("log_len"))
             d.commit_out = p(o["commit_out"])
             d.commit_summary, d.summary_base = p(o["commit_lo16"]), p(b.summary_base)
             d.summary_escapes = p(o["summary_escapes"])
@@ -266,6 +267,7 @@ class DeviceEngine:
             d.elected, d.max_term = p(o["elected"]), p(o["max_term"])
             d.elected_bits = p(o["elected_bits"]) if want_bits else None
         d.status_out = p(o["status"]) if status else None
+        d.changed_bits = p(o.get("changed_bits"))
         return d
 
     def round(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):

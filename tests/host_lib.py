@@ -48,6 +48,17 @@ def lib():
         l.rh_driver_last_step_wide.argtypes = [C.c_void_p]
         l.rh_driver_flatten64.argtypes = [C.c_void_p, i64p, i64p, i64p, u32p, i64p, C.c_uint64,
                                           i64p, i64p, i64p, i64p, i64p, C.POINTER(C.c_uint64)]
+        l.rh_driver_flagged.argtypes = [C.c_void_p, u32p, u8p, C.c_uint32]
+        l.rh_driver_flagged.restype = C.c_uint32
+        l.rh_driver_throw_if_flagged.argtypes = [C.c_void_p]
+        l.rh_resident_new.argtypes = [C.c_void_p, C.c_int]
+        l.rh_resident_roles.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_int]; l.rh_resident_roles.restype = None
+        l.rh_resident_get_roles.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        l.rh_resident_get_roles.restype = None
+        l.rh_resident_mark_dirty.argtypes = [C.c_void_p, C.c_uint32]; l.rh_resident_mark_dirty.restype = None
+        l.rh_resident_step.argtypes = [C.c_void_p, u32p]
+        l.rh_resident_flagged.argtypes = [C.c_void_p, u32p, u8p, C.c_uint32]
+        l.rh_resident_flagged.restype = C.c_uint32
         _l = l
     return _l
 
@@ -67,11 +78,41 @@ class Cluster:
             assert a.size == G
             self.h = C.c_void_p(self.l.rh_cluster_new_sizes(G, n, a.ctypes.data_as(u32p)))
 
+    resident = False
+
     def close(self):
         if self.h:
             self.l.rh_cluster_free(self.h); self.h = None
 
+    def use_resident(self, device=0):
+        """From here on roles / get_roles / step go to a ResidentDriver made from the
+        batched driver's current groups, and every helper that changes a Node marks
+        its group dirty (what a host does after applying an RPC)."""
+        assert self.l.rh_resident_new(self.h, device) == 0
+        self.resident = True
+
+    def _touch(self, g):
+        if self.resident:
+            self.l.rh_resident_mark_dirty(self.h, g)
+
+    def step_resident(self):
+        rep = (C.c_uint32 * 3)()
+        rc = self.l.rh_resident_step(self.h, rep)
+        return rc, dict(uploaded=rep[0], changed=rep[1], rebuilt=bool(rep[2]))
+
+    def flagged(self):
+        """(group, status) pairs of the last step: conditions that are Go panics in the reference."""
+        fn = self.l.rh_resident_flagged if self.resident else self.l.rh_driver_flagged
+        n = fn(self.h, None, None, 0)
+        g = np.zeros(max(n, 1), np.uint32); st = np.zeros(max(n, 1), np.uint8)
+        fn(self.h, g.ctypes.data_as(u32p), st.ctypes.data_as(u8p), n)
+        return list(zip(g[:n].tolist(), st[:n].tolist()))
+
+    def throw_if_flagged(self):
+        return bool(self.l.rh_driver_throw_if_flagged(self.h))
+
     def seed(self, g, p, term, voted_for, role, commit=0, log_terms=None):
+        self._touch(g)
         self.l.rh_node_seed(self.h, g, p, term, voted_for, role, commit)
         if log_terms is not None:
             a = (C.c_int64 * max(1, len(log_terms)))(*log_terms)
@@ -89,21 +130,27 @@ class Cluster:
         return list(nx), list(mt)
 
     def become(self, g, p, role):
+        self._touch(g)
         self.l.rh_node_become(self.h, g, p, role)
 
     def set_match(self, g, p, match):
+        self._touch(g)
         self.l.rh_leader_set_match(self.h, g, p, (C.c_int64 * self.n)(*match))
 
     def roles(self, g, leader=-1, candidate=-1):
         self.l.rh_group_roles(self.h, g, leader, candidate)
+        if self.resident:
+            self.l.rh_resident_roles(self.h, g, leader, candidate)
 
     def get_roles(self, g):
         a, b = C.c_int(), C.c_int()
-        self.l.rh_group_get_roles(self.h, g, C.byref(a), C.byref(b))
+        fn = self.l.rh_resident_get_roles if self.resident else self.l.rh_group_get_roles
+        fn(self.h, g, C.byref(a), C.byref(b))
         return a.value, b.value
 
     def request_vote(self, g, p, term, cand, lli=0, llt=0):
         tr = C.c_int64(); gr = C.c_int()
+        self._touch(g)
         rc = self.l.rh_request_vote(self.h, g, p, term, cand, lli, llt, C.byref(tr), C.byref(gr))
         return rc, tr.value, bool(gr.value)
 
@@ -111,6 +158,7 @@ class Cluster:
         ni = (C.c_int64 * max(1, len(new)))(*[e[0] for e in new])
         nt = (C.c_int64 * max(1, len(new)))(*[e[1] for e in new])
         tr = C.c_int64(); ok = C.c_int()
+        self._touch(g)
         rc = self.l.rh_append_entries(self.h, g, p, term, leader, prev_index, prev_term, ni, nt, len(new),
                                       leader_commit, C.byref(tr), C.byref(ok))
         return rc, tr.value, bool(ok.value)

@@ -388,3 +388,126 @@ def test_three_node_groups_through_a_term_on_gpu():
     def gpu_step(c):
         assert c.step(0) == 0
     _scenario_three_node_groups(gpu_step)
+
+
+@pytest.mark.gpu
+def test_three_node_groups_through_a_term_on_the_resident_driver():
+    """The same scenario with the image resident in HBM: after the first step only
+    the groups whose Nodes were touched go up and only changed groups come back."""
+    reports = []
+
+    def resident_step(c):
+        if not c.resident:
+            c.use_resident(0)
+        rc, rep = c.step_resident()
+        assert rc == 0 and not c.flagged()
+        reports.append(rep)
+    _scenario_three_node_groups(resident_step)
+    assert reports[0]["rebuilt"] and reports[0]["changed"] == 64           # every group elected its candidate
+    assert not reports[1]["rebuilt"] and reports[1]["uploaded"] == 64      # every leader took a client entry
+    assert reports[1]["changed"] == 48                                     # commitIndex moved where a follower replied
+
+
+@pytest.mark.gpu
+def test_step_reports_groups_where_the_reference_panics():
+    """A cluster fresh from NewNode has empty logs (raft.go:87): RequestVoteRPC panics
+    at lastEntry (raft.go:204, :235) after it has raised the voter's term.  The batched
+    step applies what the reference had done before the panic and lists the group; a
+    leader whose quorum index lies outside its log (log[N], the convention of
+    raft.go:151) is listed too and keeps its commitIndex."""
+    for resident in (False, True):
+        G, n = 6, 3
+        c = h.Cluster(G, n)
+        try:
+            for g in range(G):
+                for p in range(n):
+                    logs = [] if g < 2 else [0, 1]                  # groups 0, 1: straight from NewNode
+                    c.seed(g, p, 0, -1, h.FOLLOWER, 0, logs)
+            for g in (0, 1, 2):                                     # candidates at term 1
+                c.become(g, 0, 2)
+                c.seed(g, 0, 1, -1, h.CANDIDATE, 0, [] if g < 2 else [0, 1])
+                c.roles(g, leader=-1, candidate=0)
+            for g in (3, 4):                                        # leaders; group 4's followers claim index 7
+                c.become(g, 0, 0)
+                c.seed(g, 0, 1, -1, h.LEADER, 0, [0, 1])
+                c.set_match(g, 0, [7, 7, 7] if g == 4 else [1, 1, 0])
+                c.roles(g, leader=0, candidate=-1)
+            # the per-node reference calls panic for the NewNode groups
+            probe = h.Cluster(1, n)
+            assert probe.request_vote(0, 1, 1, 0)[0] == 1
+            probe.close()
+            if resident:
+                c.use_resident(0)
+                rc, _ = c.step_resident()
+            else:
+                rc = c.step(0)
+            assert rc == 0
+            assert sorted(c.flagged()) == [(0, 2), (1, 2), (4, 1)]
+            if not resident:
+                assert c.throw_if_flagged()
+            for g in (0, 1):                                        # term raised, role set, nobody elected
+                assert [c.get(g, p)["currentTerm"] for p in range(n)] == [1, 1, 1]
+                assert c.get_roles(g) == (-1, 0)
+            assert c.get_roles(2) == (0, -1)                        # the group with logs elects as usual
+            assert c.get(3, 0)["commitIndex"] == 1 and c.get(4, 0)["commitIndex"] == 0
+        finally:
+            c.close()
+
+
+@pytest.mark.gpu
+def test_resident_driver_tracks_the_oracle_over_incremental_steps():
+    """2000 five-node groups resident on the device.  Every step the host touches a few
+    hundred groups (longer leader logs, new matchIndex, a new candidate term) and marks
+    them dirty; the driver must leave the objects where the oracle's round over a fresh
+    flatten of ALL objects puts them, while moving only the touched and changed rows."""
+    G, n = 2000, 5
+    c, b = _build(G, n, seed=41)
+    rng = np.random.default_rng(9)
+    try:
+        c.use_resident(0)
+        for g in range(G):
+            c.roles(g, *c.get_roles(g))                            # same roles in both drivers
+        for it in range(5):
+            if it:
+                touched = rng.choice(G, 300, replace=False)
+                for g in touched.tolist():
+                    lead, cand = c.get_roles(g)
+                    if lead >= 0:
+                        s = c.get(g, lead)
+                        # it 2: some logs outgrow their slice and move inside the arena;
+                        # it 3: one log outgrows the arena's free space, everything is laid out afresh
+                        grow = 40 if (it == 2 and g % 10 == 0) else int(rng.integers(0, 3))
+                        if it == 3 and g == int(touched[0]):
+                            grow = 90000
+                        terms = [1 + (i * int(s["currentTerm"])) // (s["logLen"] + grow) for i in range(s["logLen"] + grow)]
+                        c.seed(g, lead, s["currentTerm"], s["votedFor"], h.LEADER, s["commitIndex"], terms)
+                        c.set_match(g, lead, [int(x) for x in rng.integers(0, s["logLen"] + grow, n)])
+                    if cand >= 0:
+                        s = c.get(g, cand)
+                        c.seed(g, cand, s["currentTerm"] + int(rng.integers(0, 2)), s["votedFor"], h.CANDIDATE, s["commitIndex"])
+            rc, f = c.flatten(log_cap=1 << 22)
+            assert rc == 0
+            exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                                f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
+            roles_before = [c.get_roles(g) for g in range(G)]
+            rc, rep = c.step_resident()
+            assert rc == 0
+            assert rep["rebuilt"] == (it in (0, 3))                 # first image; a log that outgrew the arena
+            if it in (1, 2, 4):
+                assert 300 <= rep["uploaded"] <= 300 + G            # touched groups (+ groups that elected last step)
+            moved = (exp.commit != f["commit"]) | (exp.stepdown_mask != 0) | (exp.elected != 0) | (exp.status != 0)
+            assert rep["changed"] == int(moved.sum())
+            assert sorted(c.flagged()) == sorted((int(g), int(exp.status[g])) for g in np.nonzero(exp.status)[0])
+            for g in range(G):
+                lead, cand = roles_before[g]
+                if cand >= 0:
+                    for p in range(n):
+                        assert c.get(g, p)["currentTerm"] == exp.voter_term[p, g], (it, g, p)
+                    assert (c.get_roles(g)[0] == cand) == bool(exp.elected[g]), (it, g)
+                if lead >= 0:
+                    assert c.get(g, lead)["commitIndex"] == exp.commit[g], (it, g)
+            for g in range(G):                                      # keep the batched driver's roles (used by flatten) in step
+                lead, cand = c.get_roles(g)
+                c.l.rh_group_roles(c.h, g, lead, cand)
+    finally:
+        c.close()
