@@ -353,7 +353,9 @@ def main():
         if ex is not None and s % R == R - 1:
             ex.exchange(s // R, async_op=True)   # R rounds of summaries in one collective
             if consumer is not None:
-                consumer.consume(s // R)         # device-side decode, ordered after the all-gather
+                # device-side decode of the PREVIOUS exchange: its all-gather has had a whole
+                # exchange period to finish, so the compute stream does not stall on it
+                consumer.consume((s // R - 1) % depth)
 
     def fence():
         if ex is not None:
@@ -367,21 +369,21 @@ def main():
     for i in range(S):
         step(i)
     fence()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record(); ev1.record()                # creates the events outside the timed region
     for i in range(args.warmup):
         step(i)
     fence()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
     for i in range(args.steps):
         step(i)
     ev1.record()                              # same stream as the kernels
+    t_enqueued = time.perf_counter()
     if ex is not None:
         ex.wait_all()
-    while not ev1.query():                    # poll: a blocking wait adds tens of microseconds of wake-up
-        pass                                  # latency, a tenth of a 20-step timed region
-    torch.cuda.synchronize(device)
+    torch.cuda.synchronize(device)            # (polling the event from Python was measured slower than this)
     t1 = time.perf_counter()
     if use_dist:
         dist.barrier()
@@ -443,6 +445,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kernel_ms,
+                         "host_enqueue_ms_per_step": (t_enqueued - t0) / args.steps * 1e3,
                          "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else "rq_round_joint<16,...>"},
             "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
         }

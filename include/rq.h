@@ -501,17 +501,19 @@ int rq_comm_sync(rq_comm *c);
 int rq_comm_last_error(const rq_comm *c, int *nccl_result, int *hip_error);
 
 /* Consumer side of the exchange, on the device: every rank keeps a replica of
- * every rank's commitIndex ([ranks][groups] int32) and adds one gathered round of
+ * every rank's commitIndex ([ranks][groups] int32) and adds the gathered
  * advance-coded summaries to it, without a host synchronisation.  gathered:
- * `ranks` messages of msg_stride bytes (the all-gather's receive buffer), the
- * commit section of one round at byte section_off inside each message, `bits`
- * (16, 8 or 4) bits per group as written by rq_round_dev with summary_base =
- * the round's input commit plane.  Escape values leave the replica entry alone
- * and are counted in *escapes (may be NULL; same saturating count as
- * summary_escapes): the host then fetches that round's full vector.  Enqueued
- * on `stream`; order it after the all-gather with rq_comm_wait. */
+ * `ranks` messages of msg_stride bytes (the all-gather's receive buffer); each
+ * message carries `rounds` rounds round_stride bytes apart, the commit section
+ * of a round at byte section_off inside it, `bits` (16, 8 or 4) bits per group
+ * as written by rq_round_dev with summary_base = the round's input commit
+ * plane.  All rounds of the message are summed in one launch.  Escape values add
+ * nothing and are counted in *escapes (may be NULL; same saturating count as
+ * summary_escapes): the host then fetches the full vectors of that period.
+ * Enqueued on `stream`; order it after the all-gather with rq_comm_wait. */
 int rq_summary_apply_dev(rq_engine *e, void *stream, const void *gathered, uint64_t msg_stride,
-                         uint64_t section_off, uint32_t ranks, uint32_t groups, uint32_t bits,
+                         uint64_t section_off, uint64_t round_stride, uint32_t rounds,
+                         uint32_t ranks, uint32_t groups, uint32_t bits,
                          int32_t *replica, uint32_t *escapes);
 
 #ifdef __cplusplus

@@ -83,7 +83,7 @@ PROTOTYPES = {
     "rq_round64": [vp, cint, u32, u32, u32] + [vp] * 20,
     "rq_follower_clamp64": [vp, u64, vp, vp, vp, vp],
     "rq_append_check64": [vp, u32, u32, u32] + [vp] * 14,
-    "rq_summary_apply_dev": [vp, vp, vp, u64, u64, u32, u32, u32, vp, vp],
+    "rq_summary_apply_dev": [vp, vp, vp, u64, u64, u64, u32, u32, u32, u32, vp, vp],
     "rq_fused_round_noalloc": [cint, vp, u32, u32, u32] + _COMMIT_IN + _VOTE_IN + [i32p] + _VOTE_OUT + [u8p],
     "rq_plan_launch": [vp, vp],
     "rq_plan_destroy": [vp],

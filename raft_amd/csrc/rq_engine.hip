@@ -948,12 +948,13 @@ int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d) {
 }
 
 int rq_summary_apply_dev(rq_engine *e, void *stream, const void *gathered, uint64_t msg_stride,
-                         uint64_t section_off, uint32_t ranks, uint32_t groups, uint32_t bits,
+                         uint64_t section_off, uint64_t round_stride, uint32_t rounds,
+                         uint32_t ranks, uint32_t groups, uint32_t bits,
                          int32_t *replica, uint32_t *escapes) {
     if (!e || !gathered || !replica) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = rq_launch_summary_apply((const uint8_t *)gathered, msg_stride, section_off, ranks, groups,
-                                             bits, replica, escapes, (hipStream_t)stream);
+    hipError_t err = rq_launch_summary_apply((const uint8_t *)gathered, msg_stride, section_off, round_stride,
+                                             rounds, ranks, groups, bits, replica, escapes, (hipStream_t)stream);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;

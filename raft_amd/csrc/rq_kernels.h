@@ -144,10 +144,11 @@ hipError_t rq_launch_groups_gather(const rq_round64_args &a, uint32_t n, uint32_
 
 // Summary consumer of a sharded deployment: adds the gathered narrow commit
 // summaries (advance coding) of `ranks` ranks to this rank's replica of every
-// rank's commitIndex.  msg: ranks messages of msg_stride bytes, the commit
-// section of `groups` offsets of `bits` (16, 8, 4) bits at byte offset
-// section_off; replica: [ranks][groups] int32.  Escape values leave the replica
-// entry unchanged and are counted in *escapes.
+// rank's commitIndex.  msg: ranks messages of msg_stride bytes, each holding
+// `rounds` rounds round_stride bytes apart, the commit section of a round --
+// `groups` offsets of `bits` (16, 8, 4) bits -- at byte offset section_off;
+// replica: [ranks][groups] int32.  Escape values add nothing and are counted in
+// *escapes.
 hipError_t rq_launch_summary_apply(const uint8_t *msg, uint64_t msg_stride, uint64_t section_off,
-                                   uint32_t ranks, uint32_t groups, uint32_t bits,
+                                   uint64_t round_stride, uint32_t rounds, uint32_t ranks, uint32_t groups, uint32_t bits,
                                    int32_t *replica, uint32_t *escapes, hipStream_t stream);

@@ -39,34 +39,40 @@ hipError_t rq_launch_groups_gather(const rq_round_args &a, uint32_t n, uint32_t 
 // ---------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void rq_summary_apply_kernel(const uint8_t *msg, uint64_t msg_stride,
-                                                               uint64_t section_off, uint32_t groups,
+                                                               uint64_t section_off, uint64_t round_stride,
+                                                               uint32_t rounds, uint32_t groups,
                                                                uint32_t bits, int32_t *replica,
                                                                uint32_t *escapes) {
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t r = blockIdx.y;
     uint32_t esc = 0;
     if (g < groups) {
-        const uint8_t *sec = msg + (uint64_t)r * msg_stride + section_off;
-        uint32_t v;
-        if (bits == 16) v = reinterpret_cast<const uint16_t *>(sec)[g];
-        else if (bits == 8) v = sec[g];
-        else v = (sec[g >> 1] >> (4 * (g & 1))) & 0xFu;   // little-endian words: group g in bits 4*(g%16)
         const uint32_t escape = (1u << bits) - 1u;
-        if (v == escape) esc = 1;
-        else if (v) replica[(uint64_t)r * groups + g] += (int32_t)v;
+        uint32_t sum = 0;
+        for (uint32_t k = 0; k < rounds; k++) {      // the rounds of one message, oldest first
+            const uint8_t *sec = msg + (uint64_t)r * msg_stride + section_off + (uint64_t)k * round_stride;
+            uint32_t v;
+            if (bits == 16) v = reinterpret_cast<const uint16_t *>(sec)[g];
+            else if (bits == 8) v = sec[g];
+            else v = (sec[g >> 1] >> (4 * (g & 1))) & 0xFu;   // little-endian words: group g in bits 4*(g%16)
+            if (v == escape) esc++;
+            else sum += v;
+        }
+        if (sum) replica[(uint64_t)r * groups + g] += (int32_t)sum;
     }
     if (escapes) count_escapes(esc, escapes);
 }
 }  // namespace
 
 hipError_t rq_launch_summary_apply(const uint8_t *msg, uint64_t msg_stride, uint64_t section_off,
+                                   uint64_t round_stride, uint32_t rounds,
                                    uint32_t ranks, uint32_t groups, uint32_t bits,
                                    int32_t *replica, uint32_t *escapes, hipStream_t stream) {
-    if (ranks == 0 || groups == 0) return hipSuccess;
+    if (ranks == 0 || groups == 0 || rounds == 0) return hipSuccess;
     if ((bits != 16 && bits != 8 && bits != 4) || ranks > 65535u) return hipErrorInvalidValue;
-    if (bits == 16 && ((section_off | msg_stride) & 1u)) return hipErrorInvalidValue;
+    if (bits == 16 && ((section_off | msg_stride | round_stride) & 1u)) return hipErrorInvalidValue;
     const dim3 grid((groups + 255u) / 256u, ranks), blk(256);
-    hipLaunchKernelGGL(rq_summary_apply_kernel, grid, blk, 0, stream, msg, msg_stride, section_off, groups, bits,
-                       replica, escapes);
+    hipLaunchKernelGGL(rq_summary_apply_kernel, grid, blk, 0, stream, msg, msg_stride, section_off, round_stride,
+                       rounds, groups, bits, replica, escapes);
     return hipGetLastError();
 }

@@ -269,6 +269,7 @@ class SummaryConsumer:
         assert ex.device.type == "cuda", "rq_summary_apply_dev is a GPU kernel"
         import ctypes as C
         from . import _lib
+        self._lib = _lib
         self.ex = ex
         self._l = _lib.lib()
         h = C.c_void_p()
@@ -288,12 +289,11 @@ class SummaryConsumer:
         ex = self.ex
         ex.wait(slot)
         stream = torch.cuda.current_stream(ex.device).cuda_stream
-        for sub in range(ex.rounds):
-            rc = self._l.rq_summary_apply_dev(self._h, stream, ex.all[slot].data_ptr(), ex.nbytes,
-                                              sub * ex.round_bytes, ex.world, ex.groups, ex.bits,
-                                              self.replica.data_ptr(), self.escapes.data_ptr())
-            if rc != 0:
-                raise _lib.RqError(rc, "rq_summary_apply_dev", self._l.rq_last_hip_error(self._h))
+        rc = self._l.rq_summary_apply_dev(self._h, stream, ex.all[slot].data_ptr(), ex.nbytes, 0,
+                                          ex.round_bytes, ex.rounds, ex.world, ex.groups, ex.bits,
+                                          self.replica.data_ptr(), self.escapes.data_ptr())
+        if rc != 0:
+            raise self._lib.RqError(rc, "rq_summary_apply_dev", self._l.rq_last_hip_error(self._h))
 
     def close(self):
         if self._h:

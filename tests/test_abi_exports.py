@@ -105,5 +105,5 @@ def test_device_entry_points_reject_bad_descriptors_without_a_gpu():
     assert l.rq_plan_round(None, C.byref(d), C.byref(plan)) == -1
     a = _lib.AppendDesc()
     assert l.rq_append_check_dev(None, None, C.byref(a)) == -1
-    assert l.rq_summary_apply_dev(None, None, None, 0, 0, 1, 1, 8, None, None) == -1
+    assert l.rq_summary_apply_dev(None, None, None, 0, 0, 0, 1, 1, 1, 8, None, None) == -1
 

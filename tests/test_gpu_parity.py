@@ -1146,3 +1146,119 @@ def test_summary_consumer_applies_advances_on_the_device(dev):
         assert (n_esc > 0) == (bits < 16)
         cons.close()
         ex.close()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+def test_groups_scatter_gather_and_changed_bits(dev, wide):
+    """A resident image with room behind every log: the round writes the changed-bit
+    summary; rq_groups_scatter_dev replaces some groups (their logs moved to free arena
+    space), the next round must equal the oracle on the edited batch; rq_groups_gather_dev
+    packs chosen groups' outputs; refused rows leave their group alone."""
+    import ctypes as C
+    import torch
+    from raft_amd.device import DeviceBatch
+    G, n, K = 5003, 5, 600
+    dt, tdt = (np.int64, torch.int64) if wide else (np.int32, torch.int32)
+    b = synth.gen_fused(G, n, seed=71)
+    b2 = synth.gen_fused(G, n, seed=72)
+    lens = np.diff(b.log_off.astype(np.int64))
+    cap = lens + 3
+    off = np.zeros(G + 1, np.int64); np.cumsum(cap, out=off[1:])
+    tail0 = int(off[-1])
+    arena = np.zeros(tail0 + K * 20 + 7, np.int32)
+    for g in range(G):
+        arena[off[g]: off[g] + lens[g]] = b.log_term[b.log_off[g]: b.log_off[g + 1]]
+    img = synth.Batch(b)
+    img["log_off"], img["log_term"] = off.astype(np.uint32), arena
+    batch = synth.widen(img)[0] if wide else img
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    for bits in ((None, 8) if not wide else (None,)):
+        db = DeviceBatch(batch, in_place=True, log_term_bits=bits)
+        db.t["log_len"] = up(lens.astype(np.int32))
+        db.o["changed_bits"] = torch.zeros((G + 63) // 64, dtype=torch.int64, device="cuda:0")
+        exp = o.fused_round(*b.fused_args(), G=G)
+        dev.fused_round(db)
+        res = db.results()
+        _check_dev(res, exp, G)
+        moved = (exp["commit"] != b.commit) | (exp["stepdown_mask"] != 0) | (exp["elected"] != 0) | (exp["status"] != 0)
+        got_bits = np.unpackbits(db.o["changed_bits"].cpu().numpy().view(np.uint8), bitorder="little")
+        assert np.array_equal(got_bits[:G].astype(bool), moved) and not got_bits[G:].any()
+
+        # the host edits K groups: state of b2, logs of b2 placed in the free space behind the slices
+        rng = np.random.default_rng(5)
+        gids = rng.choice(G, K, replace=False).astype(np.uint32)
+        words = 4 * n + 7
+        rows = np.zeros((K, words), dt)
+        roff = np.zeros(K + 1, np.uint32)
+        rterms, tail = [], tail0
+        cur = synth.Batch(b)                                      # what the device holds after round 1
+        cur["commit"], cur["voter_term"] = exp["commit"].copy(), exp["voter_term"].copy()
+        edited = synth.Batch({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in cur.items()})
+        new_logs = {}
+        for r, g in enumerate(gids.tolist()):
+            for j, k in enumerate(("match", "voter_term", "voted_for", "last_log_term")):
+                rows[r, j * n:(j + 1) * n] = b2[k][:, g]
+                edited[k][:, g] = b2[k][:, g]
+            t = b2.log_term[b2.log_off[g]: b2.log_off[g + 1]]
+            rows[r, 4 * n: 4 * n + 4] = (b2.commit[g], b2.leader_term[g], b2.cand_term[g], b2.cand_id[g])
+            for k in ("commit", "leader_term", "cand_term", "cand_id"):
+                edited[k][g] = b2[k][g]
+            rows[r, 4 * n + 6] = tail
+            tail += t.size + 2
+            roff[r + 1] = roff[r] + t.size
+            rterms.append(t)
+            new_logs[g] = t
+        # three refused rows: no such group, a log past the arena's end, (narrow arena) a term too wide
+        bad = np.zeros((3, words), dt)
+        bad[:, 4 * n + 6] = tail
+        bad[1, 4 * n + 6] = arena.size - 1
+        bad_g = np.array([G + 5, int(gids[0]) ^ 1 if (int(gids[0]) ^ 1) not in new_logs and (int(gids[0]) ^ 1) < G else 0,
+                          1 if 1 not in new_logs else 2], np.uint32)
+        bad_terms = [np.array([1], np.int32), np.array([1, 1, 1], np.int32), np.array([300], np.int32)]
+        all_g = np.concatenate([gids, bad_g])
+        all_rows = np.concatenate([rows, bad])
+        all_off = np.concatenate([roff, roff[-1] + np.cumsum([t.size for t in bad_terms]).astype(np.uint32)])
+        all_terms = np.concatenate(rterms + bad_terms).astype(dt)
+        d = dev.describe(db)
+        st = torch.full((K + 3,), 9, dtype=torch.uint8, device="cuda:0")
+        keep = [up(all_g.view(np.int32)), up(all_rows), up(all_off.view(np.int32)), up(all_terms)]
+        rc = dev._l.rq_groups_scatter_dev(dev._h, dev._stream(), C.byref(d), K + 3, keep[0].data_ptr(), keep[1].data_ptr(),
+                                          keep[2].data_ptr(), keep[3].data_ptr(), st.data_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        stat = st.cpu().numpy()
+        assert not stat[:K].any() and stat[K] == 4 and stat[K + 1] == 1
+        assert stat[K + 2] == (2 if db.log_term_bits == 8 else 0)
+        if stat[K + 2] == 0:                                      # that row was applied: all zeros, log [300] at `tail`
+            g = int(bad_g[2])
+            for k in ("match", "voter_term", "voted_for", "last_log_term"):
+                edited[k][:, g] = 0
+            for k in ("commit", "leader_term", "cand_term", "cand_id"):
+                edited[k][g] = 0
+            new_logs[g] = np.array([300], np.int32)
+        # the edited batch as a plain CSR for the oracle
+        logs = [new_logs.get(g, b.log_term[b.log_off[g]: b.log_off[g + 1]]) for g in range(G)]
+        edited["log_off"] = np.concatenate([[0], np.cumsum([t.size for t in logs])]).astype(np.uint32)
+        edited["log_term"] = np.concatenate(logs).astype(np.int32)
+        exp2 = o.fused_round(*edited.fused_args(), G=G)
+        dev.fused_round(db)
+        res2 = db.results()
+        _check_dev(res2, exp2, G)
+        # gather a sample of groups
+        pick = rng.choice(G, 700, replace=False).astype(np.uint32)
+        pick[0] = G + 1                                           # unknown group: zeros, every flag bit set
+        orows = torch.zeros((700, n + 2), dtype=tdt, device="cuda:0")
+        oflags = torch.zeros(700, dtype=torch.int64, device="cuda:0")
+        gp = up(pick.view(np.int32))
+        rc = dev._l.rq_groups_gather_dev(dev._h, dev._stream(), C.byref(d), 700, gp.data_ptr(), orows.data_ptr(),
+                                         oflags.data_ptr())
+        assert rc == 0
+        torch.cuda.synchronize()
+        R, F = orows.cpu().numpy(), oflags.cpu().numpy().view(np.uint64)
+        assert F[0] == np.uint64(0xFFFFFFFFFFFFFFFF) and not R[0].any()
+        p = pick[1:].astype(np.int64)
+        assert np.array_equal(R[1:, 0], res2["commit"][p]) and np.array_equal(R[1:, 1], res2["max_term"][p])
+        assert np.array_equal(R[1:, 2:], res2["voter_term"][:, p].T)
+        want = (res2["grant_mask"][p].astype(np.uint64) | (res2["stepdown_mask"][p].astype(np.uint64) << np.uint64(16))
+                | (res2["elected"][p].astype(np.uint64) << np.uint64(32)) | (res2["status"][p].astype(np.uint64) << np.uint64(40)))
+        assert np.array_equal(F[1:], want)
