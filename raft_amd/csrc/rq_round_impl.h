@@ -779,11 +779,13 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
 // ---------------------------------------------------------------------------
 // dispatch.  Builds per kernel family, element type and decision set: the
 // default (every streamed access non-temporal) and RQ_VAR_PLAIN; the log-term
-// gather of the default build is non-temporal only while the arena is short
-// (a few lines per group: the gathered line is not used again), and plain for
-// long logs, where it was measured 13 % faster.
+// gather of the default build is non-temporal only while neighbouring groups
+// share arena lines (short logs: the wave's gathers sweep the arena like one
+// more stream, measured 4 % faster at 8-34 bytes of arena per group), and plain
+// when every gather lands in a line of its own (long logs: non-temporal was
+// measured 8-13 % slower at 200 bytes - 3 KB per group).
 // ---------------------------------------------------------------------------
-constexpr uint64_t kNtGatherMaxArenaBytesPerGroup = 256;
+constexpr uint64_t kNtGatherMaxArenaBytesPerGroup = 64;
 
 template <typename K, typename T>
 hipError_t launch_grid(K kernel, const rq_round_args_t<T> &a, uint32_t block, hipStream_t s) {
