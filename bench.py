@@ -2,8 +2,9 @@
 """Benchmark of the batched Raft quorum engine on MI355X.
 
 A step = one fused round (RequestVote tally + commitIndex advance with the
-log-term gather) over this rank's 1M groups x 5 peers, inputs resident in HBM.
-Input/output sets rotate (default 12 sets, ~2.1 GB in total: both the reads
+log-term gather) over this rank's 1M groups x 5 peers, inputs resident in HBM
+(by default in 64-group tiles, one input and one output stream per wave; --planes
+keeps slot-major planes).  Input/output sets rotate (default 12 sets, ~2.1 GB in total: both the reads
 and the 36 MB of writes per step exceed the 256 MB Infinity Cache, which
 otherwise absorbs the writes of up to 5 sets and flatters the number).  Before
 anything is timed every set's prepared launch is built and one untimed rotation
@@ -102,6 +103,9 @@ def parse():
     ap.add_argument("--log-term-bits", type=int, choices=[0, 8, 16, 32], default=0,
                     help="width of the log-term arena entries; 0 = the narrowest the batch's terms fit "
                          "(what a host keeping the arena resident would choose), 32 = the plain int32 arena")
+    ap.add_argument("--planes", action="store_true",
+                    help="keep every array as a slot-major plane field[p * ld + g] instead of the default 64-group "
+                         "tiles (rq_round_desc.tile_bytes: one input and one output stream per wave)")
     ap.add_argument("--layout", choices=["i32", "i64"], default="i32",
                     help="i64: the wide layout (rq_round64_dev), values shifted beyond the int32 range")
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
@@ -196,12 +200,20 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     def frac(bytes_per_group, ms):
         return bytes_per_group * G / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS
 
+    tiled = not args.planes
     # plain int32 arena (no narrowing), otherwise the headline workload
-    sets = [DeviceBatch(b, device, log_term_bits=32) for b in host_batches]
+    sets = [DeviceBatch(b, device, log_term_bits=32, tiled=tiled) for b in host_batches]
     S = len(sets)
     ms = timed_launches(torch, device, lambda i: eng.fused_round(sets[i % S]), steps, warmup, S)
     out["arena_i32"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n), ms), input_sets=S,
                             note="log-term arena kept as int32 entries")
+    del sets
+    torch.cuda.empty_cache()
+    # the headline workload in slot-major planes (the layout of the host-buffer entry points)
+    sets = [DeviceBatch(b, device, log_term_bits=args.log_term_bits, tiled=False) for b in host_batches]
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(sets[i % S]), steps, warmup, S)
+    out["planes"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n), ms), input_sets=S,
+                         note="slot-major planes field[p * ld + g] instead of 64-group tiles")
     del sets
     torch.cuda.empty_cache()
 
@@ -209,7 +221,7 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     wide = []
     for s, b in enumerate(host_batches[:8]):
         w, _ = synth.widen(b, index_shift=0, term_shift=1 << 41, id_shift=1 << 42, seed=1000 + s)
-        wide.append(DeviceBatch(w, device))
+        wide.append(DeviceBatch(w, device, tiled=tiled))
     S = len(wide)
     ms = timed_launches(torch, device, lambda i: eng.fused_round(wide[i % S]), steps, warmup, S)
     out["i64"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n, "fused", "i64"), ms), input_sets=S,
@@ -220,9 +232,10 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
 
     # mixed 3-9 peers + 10 % joint consensus, Zipf log lengths; one log arena shared by the sets
     first = synth.gen_mixed(G, seed=500)
-    msets = [DeviceBatch(first, device)]
+    msets = [DeviceBatch(first, device, tiled=tiled)]
     for s in range(1, 8):
-        msets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), device, share_log_with=msets[0]))
+        msets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), device, share_log_with=msets[0],
+                                 tiled=tiled))
     mem = (first.old_mask | first.new_mask).astype(np.int64)
     members = float(sum((mem >> p) & 1 for p in range(16)).mean())
     bpg = 20 * members + 41
@@ -322,6 +335,9 @@ def main():
             kw["share_log_with"] = sets[0]
         if args.layout == "i32" and args.workload == "fused":
             kw["log_term_bits"] = args.log_term_bits
+        tiled = not args.planes and not (ex is not None and args.summary == "i32")   # full vectors land in plain arrays
+        if tiled:
+            kw["tiled"] = True
         if ex is not None and args.summary == "i32":
             kw.update(commit_out=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R))
         elif ex is not None:
@@ -440,7 +456,7 @@ def main():
                        "rounds_per_allgather": R if ex is not None else None,
                        "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what,
                        "ld_pad": args.ld_pad, "log_window": args.log_window, "layout": args.layout,
-                       "log_term_bits": log_term_bits,
+                       "log_term_bits": log_term_bits, "tiled": bool(getattr(sets[0], "tile_bytes", 0)),
                        "alg_bytes_per_group": bytes_per_group},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,

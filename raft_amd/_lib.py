@@ -26,7 +26,7 @@ class RoundDesc(C.Structure):
     """rq_round_desc (include/rq.h); every pointer is a raw device address."""
     _fields_ = [("struct_size", u32), ("layout", u32), ("what", u32), ("variant", C.c_int32),
                 ("G", u32), ("n", u32), ("ld", u32), ("log_term_bits", u32), ("summary_bits", u32),
-                ("reserved", u32), ("log_terms", u64),
+                ("reserved", u32), ("log_terms", u64), ("tile_bytes", u64), ("out_tile_bytes", u64),
                 ("old_mask", vp), ("new_mask", vp),
                 ("match", vp), ("commit", vp), ("leader_term", vp), ("log_off", vp),
                 ("log_term", vp), ("log_base", vp), ("log_term_base", vp), ("log_len", vp),

@@ -291,7 +291,7 @@ template <typename T>
 int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     const uint32_t what = d.what;
     if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (what & ~(uint32_t)(RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return RQ_E_ARG;
-    if (d.n < 1 || d.n > RQ_MAX_SLOTS || d.ld < d.G || d.G > 0x7FFFFFFFu || d.reserved != 0) return RQ_E_ARG;
+    if (d.n < 1 || d.n > RQ_MAX_SLOTS || (d.ld < d.G && !d.tile_bytes) || d.G > 0x7FFFFFFFu || d.reserved != 0) return RQ_E_ARG;
     if ((d.old_mask == nullptr) != (d.new_mask == nullptr)) return RQ_E_ARG;
     if (what & RQ_WHAT_COMMIT) {
         if (!d.match || !d.commit || !d.leader_term || !d.log_off || !d.commit_out) return RQ_E_ARG;
@@ -312,8 +312,9 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
         const uintptr_t p = reinterpret_cast<uintptr_t>(d.commit_summary);
         if ((sb == 16 && (p & 1)) || (sb == 4 && (p & 7))) return RQ_E_ARG;
     }
+    if ((d.tile_bytes & 7u) || (d.out_tile_bytes & 7u) || ((d.out_tile_bytes != 0) != (d.tile_bytes != 0))) return RQ_E_ARG;
     std::memset(&a, 0, sizeof a);
-    a.G = d.G; a.ld = d.ld; a.m = d.n;
+    a.G = d.G; a.ld = d.ld; a.m = d.n; a.tile_bytes = d.tile_bytes; a.out_tile_bytes = d.out_tile_bytes;
     a.old_mask = d.old_mask; a.new_mask = d.new_mask;
     a.match = (const T *)d.match; a.commit = (const T *)d.commit; a.leader_term = (const T *)d.leader_term;
     a.log_off = d.log_off; a.log_term = d.log_term;
@@ -916,6 +917,7 @@ int rq_groups_scatter_dev(rq_engine *e, void *stream, const rq_round_desc *d, ui
                           const void *row_log_terms, uint8_t *row_status) {
     rq_plan p;
     RQ_TRY(plan_from_desc(e, d, p));
+    if (d->tile_bytes) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
     hipError_t err = p.wide
         ? rq_launch_groups_scatter(p.args64, p.n, count, gids, (const int64_t *)rows, row_log_off,
@@ -931,6 +933,7 @@ int rq_groups_gather_dev(rq_engine *e, void *stream, const rq_round_desc *d, uin
                          const uint32_t *gids, void *rows_out, uint64_t *flags_out) {
     rq_plan p;
     RQ_TRY(plan_from_desc(e, d, p));
+    if (d->tile_bytes) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
     hipError_t err = p.wide
         ? rq_launch_groups_gather(p.args64, p.n, count, gids, (int64_t *)rows_out, flags_out, (hipStream_t)stream)

@@ -13,6 +13,8 @@ struct rq_round_args_t {
     uint32_t G;
     uint32_t ld;
     uint32_t m;  // joint kernels: number of slot planes
+    uint64_t tile_bytes;      // 0 = planes field[p * ld + g]; else 64-group tiles of this many bytes (rq_round_impl.h)
+    uint64_t out_tile_bytes;  // stride of the tiles that hold the output arrays
     // commit side (Node.matchIndex / commitIndex / currentTerm / log, raft.go:35-68)
     const T *match;
     const T *commit;

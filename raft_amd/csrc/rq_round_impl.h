@@ -348,6 +348,32 @@ __device__ __forceinline__ typename std::make_unsigned<T>::type window_slot(T nq
 }
 
 // ---------------------------------------------------------------------------
+// Where group g's element of a field lives.  Plane layout: field[p * ld + g].
+// Tiled layout (a.tile_bytes != 0): the groups are cut into tiles of 64, a tile
+// holds its 64 groups' elements of every input field back to back (tile_bytes
+// per tile; the outputs likewise in a block of their own, out_tile_bytes per
+// tile), a field pointer names the field's place inside tile 0, slot p of a
+// field follows slot p - 1 after 64 elements -- so a wave reads one contiguous
+// tile and writes one instead of touching 26 planes 4 MiB apart.  Reads and
+// writes in separate address streams: one mixed tile gained nothing, two
+// blocks 5 % at 1M x 5.
+// ---------------------------------------------------------------------------
+struct group_addr {
+    size_t tile_off;     // bytes
+    size_t slot_stride;  // elements
+    size_t lane;         // elements
+};
+template <typename T>
+__device__ __forceinline__ group_addr addr_of(const rq_round_args_t<T> &a, uint32_t g) {
+    if (a.tile_bytes) return group_addr{(size_t)(g >> 6) * a.tile_bytes, 64, g & 63u};
+    return group_addr{0, a.ld, g};
+}
+template <typename P>
+__device__ __forceinline__ P *at(P *base, const group_addr &ga, uint32_t p = 0) {
+    return reinterpret_cast<P *>(reinterpret_cast<uintptr_t>(base) + ga.tile_off) + (p * ga.slot_stride + ga.lane);
+}
+
+// ---------------------------------------------------------------------------
 // fixed cluster size n = N for every group
 // ---------------------------------------------------------------------------
 template <int N, int V, int WHAT, bool NT, bool NTG, bool FULL, typename T>
@@ -357,7 +383,12 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     constexpr bool NTL = NT, NTS = NT;
     constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
     constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
-    const size_t ld = a.ld;
+    const group_addr ga = addr_of(a, g0);
+    group_addr go = ga;                       // outputs: their own tile block ...
+    if (a.tile_bytes) go.tile_off = (size_t)(g0 >> 6) * a.out_tile_bytes;
+    // ... unless they are the inputs themselves (state updated in place)
+    const group_addr gco = (const void *)a.commit_out == (const void *)a.commit ? ga : go;
+    const group_addr gvo = (const void *)a.voter_term_out == (const void *)a.voter_term ? ga : go;
 
     T mt[N][V], cm[V], lt[V], lb[V], tb[V];
     int32_t off[V + 1], ln[V];
@@ -371,18 +402,18 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     // ---- issue every streamed load up front ----
     if constexpr (DO_COMMIT) {
 #pragma unroll
-        for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
-        ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
-        ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
-        if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
-        if (a.log_term_base) ld_i32<V, NTL, FULL>(a.log_term_base + g0, valid, tb);
-        if (a.log_len) ld_i32<V, NTL, FULL>(reinterpret_cast<const int32_t *>(a.log_len) + g0, valid, ln);
-        const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
+        for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
+        ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
+        ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
+        if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
+        if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
+        if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
+        const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
         int32_t o[V];
         ld_i32<V, NTL, FULL>(offp, valid, o);
         // plain on purpose: it re-reads the line the vector load above brought in
         // (non-temporal here bypasses L1 and was measured 1 us slower per round)
-        const int32_t oend = offp[valid];  // log_off has G+1 entries
+        const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));  // log_off has G+1 entries
 #pragma unroll
         for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
         off[V] = oend;
@@ -390,12 +421,12 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     if constexpr (DO_VOTE) {
 #pragma unroll
         for (int p = 0; p < N; p++) {
-            ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, vt[p]);
-            ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, vf[p]);
-            ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, ll[p]);
+            ld_i32<V, NTL, FULL>(at(a.voter_term, ga, p), valid, vt[p]);
+            ld_i32<V, NTL, FULL>(at(a.voted_for, ga, p), valid, vf[p]);
+            ld_i32<V, NTL, FULL>(at(a.last_log_term, ga, p), valid, ll[p]);
         }
-        ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
-        ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
+        ld_i32<V, NTL, FULL>(at(a.cand_term, ga), valid, ct);
+        ld_i32<V, NTL, FULL>(at(a.cand_id, ga), valid, ci);
     }
 
     // ---- commit: quorum index, then the dependent log-term gather ----
@@ -440,7 +471,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
                 mx[k] = tmax(mx[k], nt[k]);
                 st[k] |= pn ? kStEmptyLog : 0;
             }
-            st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
+            st_i32<V, NTS, FULL>(at(a.voter_term_out, gvo, p), valid, nt);
         }
 #pragma unroll
         for (int k = 0; k < V; k++) {
@@ -448,10 +479,10 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             if (k < valid) el_field |= el[k] << k;
             if (k < valid) ch_field |= (uint32_t)(el[k] != 0 || sm[k] != 0) << k;
         }
-        st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
-        st_u16<V, NTS, FULL>(a.stepdown_mask + g0, valid, sm);
-        st_u8<V, NTS, FULL>(a.elected + g0, valid, el);
-        st_i32<V, NTS, FULL>(a.max_term + g0, valid, mx);
+        st_u16<V, NTS, FULL>(at(a.grant_mask, go), valid, gm);
+        st_u16<V, NTS, FULL>(at(a.stepdown_mask, go), valid, sm);
+        st_u8<V, NTS, FULL>(at(a.elected, go), valid, el);
+        st_i32<V, NTS, FULL>(at(a.max_term, go), valid, mx);
     }
 
     // ---- commit: finish ----
@@ -463,10 +494,10 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
             if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
-        st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
+        st_i32<V, NTS, FULL>(at(a.commit_out, gco), valid, co);
         if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm, esc_field);
     }
-    if (a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
+    if (a.status_out) st_u8<V, NTS, FULL>(at(a.status_out, go), valid, st);
 #pragma unroll
     for (int k = 0; k < V; k++)
         if (k < valid) ch_field |= (uint32_t)(st[k] != 0) << k;
@@ -546,7 +577,12 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
     constexpr bool NTL = NT, NTS = NT;
     constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
     constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
-    const size_t ld = a.ld;
+    const group_addr ga = addr_of(a, g0);
+    group_addr go = ga;                       // outputs: their own tile block ...
+    if (a.tile_bytes) go.tile_off = (size_t)(g0 >> 6) * a.out_tile_bytes;
+    // ... unless they are the inputs themselves (state updated in place)
+    const group_addr gco = (const void *)a.commit_out == (const void *)a.commit ? ga : go;
+    const group_addr gvo = (const void *)a.voter_term_out == (const void *)a.voter_term ? ga : go;
     const uint32_t m = a.m;
     const uint32_t lim = m >= 16 ? 0xFFFFu : ((1u << m) - 1u);
 
@@ -554,8 +590,8 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
     uint32_t anymem = 0;
     if (in_range) {
         if (a.old_mask) {
-            ld_u16<V, FULL>(a.old_mask + g0, valid, om);
-            ld_u16<V, FULL>(a.new_mask + g0, valid, nm);
+            ld_u16<V, FULL>(at(a.old_mask, ga), valid, om);
+            ld_u16<V, FULL>(at(a.new_mask, ga), valid, nm);
         } else {
 #pragma unroll
             for (int k = 0; k < V; k++) om[k] = nm[k] = (k < valid) ? lim : 0;
@@ -597,9 +633,9 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             for (int k = 0; k < V; k++) { cvt[q][k] = 0; cvf[q][k] = 0; cll[q][k] = 0; }
             if (p < MMAX && ((wm >> p) & 1u)) {
                 if ((anymem >> p) & 1u) {
-                    ld_i32<V, NTL, FULL>(a.voter_term + p * ld + g0, valid, cvt[q]);
-                    ld_i32<V, NTL, FULL>(a.voted_for + p * ld + g0, valid, cvf[q]);
-                    ld_i32<V, NTL, FULL>(a.last_log_term + p * ld + g0, valid, cll[q]);
+                    ld_i32<V, NTL, FULL>(at(a.voter_term, ga, p), valid, cvt[q]);
+                    ld_i32<V, NTL, FULL>(at(a.voted_for, ga, p), valid, cvf[q]);
+                    ld_i32<V, NTL, FULL>(at(a.last_log_term, ga, p), valid, cll[q]);
                 }
             }
         }
@@ -628,11 +664,11 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
                 }
             }
             if (all_members) {
-                st_i32<V, NTS, FULL>(a.voter_term_out + p * ld + g0, valid, nt);
+                st_i32<V, NTS, FULL>(at(a.voter_term_out, gvo, p), valid, nt);
             } else {
 #pragma unroll
                 for (int k = 0; k < V; k++)
-                    if (k < valid && ((mem[k] >> p) & 1u)) a.voter_term_out[p * ld + g0 + k] = nt[k];
+                    if (k < valid && ((mem[k] >> p) & 1u)) at(a.voter_term_out, gvo, p)[k] = nt[k];
             }
         }
     };
@@ -640,8 +676,8 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
 #pragma unroll
         for (int k = 0; k < V; k++) { ct[k] = 0; ci[k] = 0; gm[k] = 0; sm[k] = 0; mx[k] = kMinOf<T>; }
         if (in_range) {
-            ld_i32<V, NTL, FULL>(a.cand_term + g0, valid, ct);
-            ld_i32<V, NTL, FULL>(a.cand_id + g0, valid, ci);
+            ld_i32<V, NTL, FULL>(at(a.cand_term, ga), valid, ct);
+            ld_i32<V, NTL, FULL>(at(a.cand_id, ga), valid, ci);
         }
         issue_chunk(0);
     }
@@ -656,7 +692,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
 #pragma unroll
             for (int k = 0; k < V; k++) mt[p][k] = 0;
             if ((wm >> p) & 1u) {
-                if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(a.match + p * ld + g0, valid, mt[p]);
+                if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
             }
         }
         T lb[V], tb[V];
@@ -665,15 +701,15 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; tb[k] = 0; ln[k] = 0; }
         off[V] = 0;
         if (in_range) {
-            ld_i32<V, NTL, FULL>(a.commit + g0, valid, cm);
-            ld_i32<V, NTL, FULL>(a.leader_term + g0, valid, lt);
-            if (a.log_base) ld_i32<V, NTL, FULL>(a.log_base + g0, valid, lb);
-            if (a.log_term_base) ld_i32<V, NTL, FULL>(a.log_term_base + g0, valid, tb);
-            if (a.log_len) ld_i32<V, NTL, FULL>(reinterpret_cast<const int32_t *>(a.log_len) + g0, valid, ln);
-            const int32_t *offp = reinterpret_cast<const int32_t *>(a.log_off) + g0;
+            ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
+            ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
+            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
+            if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
+            if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
+            const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
             int32_t o[V];
             ld_i32<V, NTL, FULL>(offp, valid, o);
-            const int32_t oend = offp[valid];
+            const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));
 #pragma unroll
             for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
             off[V] = oend;
@@ -726,10 +762,10 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             if (k < valid) ch_field |= (uint32_t)(el[k] != 0 || sm[k] != 0) << k;
         }
         if (in_range) {
-            st_u16<V, NTS, FULL>(a.grant_mask + g0, valid, gm);
-            st_u16<V, NTS, FULL>(a.stepdown_mask + g0, valid, sm);
-            st_u8<V, NTS, FULL>(a.elected + g0, valid, el);
-            st_i32<V, NTS, FULL>(a.max_term + g0, valid, mx);
+            st_u16<V, NTS, FULL>(at(a.grant_mask, go), valid, gm);
+            st_u16<V, NTS, FULL>(at(a.stepdown_mask, go), valid, sm);
+            st_u8<V, NTS, FULL>(at(a.elected, go), valid, el);
+            st_i32<V, NTS, FULL>(at(a.max_term, go), valid, mx);
         }
     }
 
@@ -742,11 +778,11 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
         if (in_range) {
-            st_i32<V, NTS, FULL>(a.commit_out + g0, valid, co);
+            st_i32<V, NTS, FULL>(at(a.commit_out, gco), valid, co);
             if (a.commit_lo16) nib_field = store_commit_summary<V, NTS, FULL>(a, g0, valid, co, cm, esc_field);
         }
     }
-    if (in_range && a.status_out) st_u8<V, NTS, FULL>(a.status_out + g0, valid, st);
+    if (in_range && a.status_out) st_u8<V, NTS, FULL>(at(a.status_out, go), valid, st);
 #pragma unroll
     for (int k = 0; k < V; k++)
         if (k < valid) ch_field |= (uint32_t)(st[k] != 0) << k;
@@ -839,7 +875,7 @@ template <typename T>
 hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool joint, int what,
                              int variant, hipStream_t stream) {
     if (args.G == 0) return hipSuccess;
-    if (args.G > 0x7FFFFFFFu || args.ld < args.G) return hipErrorInvalidValue;
+    if (args.G > 0x7FFFFFFFu || (args.ld < args.G && !args.tile_bytes)) return hipErrorInvalidValue;
     if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
     if (args.commit_lo16 && args.summary_bits != 16 && args.summary_bits != 8 && args.summary_bits != 4)
         return hipErrorInvalidValue;

@@ -84,7 +84,7 @@ class DeviceBatch:
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
                  share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None,
-                 summary_bits=16, log_term_bits=None, log_term_base=False):
+                 summary_bits=16, log_term_bits=None, log_term_base=False, tiled=False):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         share_log_with: another DeviceBatch whose log_off/log_term device arrays
@@ -97,7 +97,10 @@ class DeviceBatch:
         log_term_bits: width of the log-term arena entries on the device: None =
         the layout's own element (int32 / int64), 0 = the narrowest that fits, or
         8 / 16 / 32; log_term_base=True stores differences from each group's
-        smallest resident term and uploads that base plane (encode_log_terms)."""
+        smallest resident term and uploads that base plane (encode_log_terms).
+        tiled=True keeps every per-group and per-slot array, inputs and outputs, in
+        ONE block of 64-group tiles (rq_round_desc.tile_bytes) instead of separate
+        slot-major planes; the log arena and the bit summaries stay plain arrays."""
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
         G, n, ld = self.G, self.n, self.ld
@@ -117,8 +120,8 @@ class DeviceBatch:
             if tbase is not None:
                 host["log_term_base"] = np.ascontiguousarray(tbase, dtype=vdt)
         for k in self.IN_KEYS:
-            if share_log_with is not None and k in ("log_off", "log_term"):
-                continue
+            if share_log_with is not None and (k == "log_term" or (k == "log_off" and not tiled)):
+                continue                        # (a tiled batch keeps its offsets inside its own tiles)
             a = batch[k]
             if k == "log_term" and enc_term is not None:
                 a = enc_term
@@ -137,16 +140,27 @@ class DeviceBatch:
                 ("elected", (G,), torch.uint8), ("max_term", (G,), tdt),
                 ("status", (G,), torch.uint8), ("elected_bits", ((G + 63) // 64,), torch.int64)]
         self.t, o = {}, {}
-        for k, a in host.items():
-            self.t[k] = torch.from_numpy(a).to(self.device)
-        for k, shape, dt in outs:
-            o[k] = torch.zeros(shape, dtype=dt, device=self.device)
+        self.tile_bytes = 0
+        if tiled:
+            assert commit_out is None, "a tiled batch keeps commit_out inside its tiles"
+            self._tile_layout(host, outs, in_place)
+            for k in ("log_term",):
+                if k in host:
+                    self.t[k] = torch.from_numpy(host[k]).to(self.device)
+            o.update(self._tile_out)
+            o["elected_bits"] = torch.zeros((G + 63) // 64, dtype=torch.int64, device=self.device)
+        else:
+            for k, a in host.items():
+                self.t[k] = torch.from_numpy(a).to(self.device)
+            for k, shape, dt in outs:
+                o[k] = torch.zeros(shape, dtype=dt, device=self.device)
         if share_log_with is not None:
-            self.t["log_off"] = share_log_with.t["log_off"]
+            if not tiled:
+                self.t["log_off"] = share_log_with.t["log_off"]
             self.t["log_term"] = share_log_with.t["log_term"]
             if "log_term_base" in share_log_with.t:
                 self.t["log_term_base"] = share_log_with.t["log_term_base"]
-        if in_place:
+        if in_place and not tiled:
             o["commit_out"] = self.t["commit"]
             o["voter_term_out"] = self.t["voter_term"]
         if commit_out is not None:
@@ -168,11 +182,78 @@ class DeviceBatch:
         self._args = {}
         self._plans = []
 
+    def _tile_layout(self, host, outs, in_place):
+        """Two blocks of ceil((G+1)/64) tiles, one for the input arrays and one for the
+        outputs (reads and writes in separate address streams); a tile holds, back to
+        back, slots x 64 elements of each of its arrays (widest elements first, so
+        everything stays aligned).  self.t / self._tile_out map names to 1-D byte
+        views that start at the array's place inside tile 0 of its block (what the
+        descriptor's pointers name)."""
+        G = self.G
+        np_of = {torch.int32: np.int32, torch.int64: np.int64, torch.int16: np.int16, torch.uint8: np.uint8}
+        ins, outf = [], []                            # (name, slots, numpy dtype, host array)
+        for k, a in host.items():
+            if k != "log_term":
+                ins.append((k, a.shape[0] if a.ndim == 2 else 1, a.dtype, a))
+        for k, shape, dt in outs:
+            if k == "elected_bits" or (in_place and k in ("commit_out", "voter_term_out")):
+                continue
+            outf.append((k, shape[0] if len(shape) == 2 else 1, np.dtype(np_of[dt]), None))
+        ntiles = (G + 1 + 63) // 64                   # log_off has G + 1 entries
+
+        def lay(fields):
+            fields.sort(key=lambda f: -f[2].itemsize)
+            off, place = 0, {}
+            for k, slots, dt, _ in fields:
+                place[k] = (off, slots, dt)
+                off += slots * 64 * dt.itemsize
+            return place, (off + 255) // 256 * 256
+
+        in_place_of, self.tile_bytes = lay(ins)
+        out_place_of, self.out_tile_bytes = lay(outf)
+        block = np.zeros((ntiles, self.tile_bytes), np.uint8)
+        for k, slots, dt, a in ins:
+            a2 = a.reshape(slots, -1)
+            pad = np.zeros((slots, ntiles * 64), dt)
+            cols = min(a2.shape[1], ntiles * 64)
+            pad[:, :cols] = a2[:, :cols]
+            off = in_place_of[k][0]
+            view = block[:, off: off + slots * 64 * dt.itemsize].view(dt).reshape(ntiles, slots, 64)
+            view[...] = pad.reshape(slots, ntiles, 64).transpose(1, 0, 2)
+        self._tile_block = torch.from_numpy(block.reshape(-1)).to(self.device)
+        self._out_block = torch.zeros(ntiles * self.out_tile_bytes, dtype=torch.uint8, device=self.device)
+        self._tile_fields = {}                        # name -> (block is the output block, offset, slots, dtype)
+        self._tile_out = {}
+        for k, (off, slots, dt) in in_place_of.items():
+            self.t[k] = self._tile_block[off:]
+            self._tile_fields[k] = (False, off, slots, dt)
+        for k, (off, slots, dt) in out_place_of.items():
+            self._tile_out[k] = self._out_block[off:]
+            self._tile_fields[k] = (True, off, slots, dt)
+        if in_place:
+            self._tile_out["commit_out"] = self.t["commit"]
+            self._tile_out["voter_term_out"] = self.t["voter_term"]
+            self._tile_fields["commit_out"] = self._tile_fields["commit"]
+            self._tile_fields["voter_term_out"] = self._tile_fields["voter_term"]
+
+    def _untile(self, blocks, name):
+        """Array `name` out of the downloaded tile blocks: [slots, G] for the voter
+        terms, [G] for per-group arrays."""
+        is_out, off, slots, dt = self._tile_fields[name]
+        block = blocks[1] if is_out else blocks[0]
+        ntiles = block.shape[0]
+        v = block[:, off: off + slots * 64 * dt.itemsize].view(dt).reshape(ntiles, slots, 64)
+        a = v.transpose(1, 0, 2).reshape(slots, ntiles * 64)[:, : self.G]
+        return a.copy() if name == "voter_term_out" else a[0].copy()
+
     def __del__(self):
         for l, plan in getattr(self, "_plans", []):
             l.rq_plan_destroy(plan)
 
     def bytes_resident(self):
+        if self.tile_bytes:
+            rest = [self.t.get("log_term"), self.o.get("elected_bits"), self.o.get("commit_lo16")]
+            return self._tile_block.numel() + self._out_block.numel() + sum(x.numel() * x.element_size() for x in rest if x is not None)
         return sum(x.numel() * x.element_size() for x in list(self.t.values()) + list(self.o.values())
                    if x is not None)
 
@@ -180,6 +261,19 @@ class DeviceBatch:
         """Outputs as numpy arrays with the C-ABI dtypes."""
         torch.cuda.synchronize(self.device)
         o = self.o
+        if self.tile_bytes:
+            blk = (self._tile_block.cpu().numpy().reshape(-1, self.tile_bytes),
+                   self._out_block.cpu().numpy().reshape(-1, self.out_tile_bytes))
+            return dict(
+                commit=self._untile(blk, "commit_out"), voter_term=self._untile(blk, "voter_term_out"),
+                grant_mask=self._untile(blk, "grant_mask").view(np.uint16),
+                stepdown_mask=self._untile(blk, "stepdown_mask").view(np.uint16),
+                elected=self._untile(blk, "elected"), max_term=self._untile(blk, "max_term"),
+                status=self._untile(blk, "status"),
+                elected_bits=o["elected_bits"].cpu().numpy().view(np.uint64),
+                commit_lo16=None if o["commit_lo16"] is None else decode_summary(
+                    o["commit_lo16"].cpu().numpy(), self.G, self.summary_bits),
+                summary_escapes=None if o["summary_escapes"] is None else int(o["summary_escapes"].cpu()[0]))
         return dict(
             commit=o["commit_out"].cpu().numpy(),
             voter_term=o["voter_term_out"].cpu().numpy(),
@@ -249,6 +343,7 @@ class DeviceEngine:
         d.layout = LAYOUT_I64 if b.wide else LAYOUT_I32
         d.what, d.variant = what, variant
         d.G, d.n, d.ld = b.G, b.n, b.ld
+        d.tile_bytes, d.out_tile_bytes = b.tile_bytes, getattr(b, "out_tile_bytes", 0)
         d.log_term_bits, d.log_terms = b.log_term_bits, b.log_terms
         d.summary_bits = b.summary_bits
         d.old_mask, d.new_mask = p(t.get("old_mask")), p(t.get("new_mask"))

@@ -1262,3 +1262,50 @@ def test_groups_scatter_gather_and_changed_bits(dev, wide):
         want = (res2["grant_mask"][p].astype(np.uint64) | (res2["stepdown_mask"][p].astype(np.uint64) << np.uint64(16))
                 | (res2["elected"][p].astype(np.uint64) << np.uint64(32)) | (res2["status"][p].astype(np.uint64) << np.uint64(40)))
         assert np.array_equal(F[1:], want)
+
+
+@pytest.mark.parametrize("kind", ["fixed", "joint", "wide"])
+def test_tiled_layout(dev, kind):
+    """Every array of a round in 64-group tiles (rq_round_desc.tile_bytes) instead of
+    slot-major planes: same decisions, out of place and in place, group counts that
+    do not fill the last tile, with log window, narrow arena and narrow summary."""
+    import torch
+    from raft_amd.device import DeviceBatch, summary_buffer_bytes
+    for G in (1, 63, 64, 65, 4099, 70001):
+        for n in ((3, 5, 9, 12) if kind != "joint" else (16,)):
+            if kind == "joint":
+                b = synth.gen_mixed(G, seed=G)
+                kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
+                mem = member_matrix(b)
+            else:
+                b = (synth.gen_adversarial if n == 9 else synth.gen_fused)(G, n, seed=G + n, ld=G + 5)
+                kw, mem = {}, None
+            if n == 5:
+                b = synth.window_logs(b, keep_committed=1)
+                kw["log_base"] = b.log_base
+            exp = o.fused_round(*b.fused_args(), G=G, **kw)
+            batch = synth.widen(b)[0] if kind == "wide" else b
+            buf = torch.zeros(summary_buffer_bytes(G, 8) + 8, dtype=torch.uint8, device="cuda:0")
+            esc = torch.zeros(2, dtype=torch.int32, device="cuda:0")
+            for in_place in (False, True):
+                db = DeviceBatch(batch, tiled=True, in_place=in_place, log_term_bits=0 if n != 9 else None,
+                                 commit_lo16=buf, summary_escapes=esc, summary_bits=8, summary_base="commit")
+                assert db.tile_bytes and db.tile_bytes % 256 == 0 and db.out_tile_bytes % 256 == 0
+                dev.fused_round(db)
+                res = db.results()
+                _check_dev(res, exp, G, mem)
+                adv = exp["commit"].astype(np.int64) - b.commit[:G]
+                fit = (adv >= 0) & (adv < 255)
+                assert np.array_equal(res["commit_lo16"], np.where(fit, adv, 255).astype(np.uint16))
+            if kind == "fixed" and n == 3:
+                dc = DeviceBatch(batch, tiled=True)
+                dev.commit_advance(dc); dev.vote_tally(dc)
+                _check_dev(dc.results(), exp, G)
+    # the single-group calls work on planes only
+    import ctypes as C
+    d = dev.describe(db)
+    assert dev._l.rq_groups_gather_dev(dev._h, None, C.byref(d), 1, None, None, None) == -1
+    d.tile_bytes = 100
+    assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == -1        # not a multiple of 8
+    d.tile_bytes, d.out_tile_bytes = db.tile_bytes, 0
+    assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == -1        # the outputs need their block's stride
