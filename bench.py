@@ -52,12 +52,17 @@ def alg_bytes_per_group(n, what="fused", layout="i32"):
 
 
 def kernel_source_hash():
-    """Fingerprint of the round kernels' source: a PMC traffic figure taken from a
-    profile is only attached to a run of the same kernel source."""
+    """Fingerprint of the round kernels' code (comments and white space stripped, so
+    rewording a comment does not detach a profile): a PMC traffic figure taken from a
+    profile is only attached to a run of the same kernel code."""
+    import re
     h = hashlib.sha1()
     for rel in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, rel), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, rel), "r") as f:
+            text = f.read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        h.update(re.sub(r"\s+", "", text).encode())
     return h.hexdigest()[:16]
 
 

@@ -817,11 +817,12 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
 // default (every streamed access non-temporal) and RQ_VAR_PLAIN; the log-term
 // gather of the default build is non-temporal only while neighbouring groups
 // share arena lines (short logs: the wave's gathers sweep the arena like one
-// more stream, measured 4 % faster at 8-34 bytes of arena per group), and plain
+// more stream, measured 4 % faster at 8-34 bytes of arena per group and 2 %
+// faster at 68 bytes, the int64 arena of the same short logs), and plain
 // when every gather lands in a line of its own (long logs: non-temporal was
 // measured 8-13 % slower at 200 bytes - 3 KB per group).
 // ---------------------------------------------------------------------------
-constexpr uint64_t kNtGatherMaxArenaBytesPerGroup = 64;
+constexpr uint64_t kNtGatherMaxArenaBytesPerGroup = 128;
 
 template <typename K, typename T>
 hipError_t launch_grid(K kernel, const rq_round_args_t<T> &a, uint32_t block, hipStream_t s) {
