@@ -116,6 +116,9 @@ def parse():
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
     ap.add_argument("--no-status", action="store_true", help="skip the per-group status byte output")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
+    ap.add_argument("--preheat-rotations", type=int, default=8,
+                    help="untimed passes over all input sets before --warmup (the first builds every "
+                         "prepared launch and touches every buffer)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
 
@@ -387,7 +390,8 @@ def main():
         torch.cuda.synchronize(device)
 
     # untimed: build every set's prepared launch and touch every buffer once
-    for i in range(S):
+    preheat = S * max(1, args.preheat_rotations)
+    for i in range(preheat):
         step(i)
     fence()
     ev0 = torch.cuda.Event(enable_timing=True)
@@ -404,8 +408,9 @@ def main():
     t_enqueued = time.perf_counter()
     if ex is not None:
         ex.wait_all()
-    torch.cuda.synchronize(device)            # (polling the event from Python was measured slower than this)
+    eng.stream_sync()                         # polls the kernels' stream: a blocked thread wakes 10-20 us late
     t1 = time.perf_counter()
+    torch.cuda.synchronize(device)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize(device)
@@ -449,7 +454,7 @@ def main():
             "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "int64" if args.layout == "i64" else "int32", "data": "synthetic",
             "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
-                       "preheat_rounds": S,
+                       "preheat_rounds": preheat,
                        "resident_mb_per_gpu": round(resident_mb, 1),
                        "rccl_ranks": dist.get_world_size() if use_dist else 1,
                        "backend": args.backend if use_dist else None, "devices": devices,

@@ -416,6 +416,11 @@ int rq_groups_scatter_dev(rq_engine *e, void *stream, const rq_round_desc *d, ui
 int rq_groups_gather_dev(rq_engine *e, void *stream, const rq_round_desc *d, uint32_t count,
                          const uint32_t *gids, void *rows_out, uint64_t *flags_out);
 
+/* Blocks the calling thread until everything enqueued on `stream` has finished
+ * (the device-pointer calls above only enqueue).  Polls the stream for the first
+ * two milliseconds before it blocks, so that a host loop over short rounds does
+ * not pay a thread wake-up per round.  No counterpart in the reference, whose
+ * calls are synchronous (raft.go:132, 181). */
 int rq_stream_sync(rq_engine *e, void *stream);
 
 /* rq_fused_round for callers that cannot allocate.  It has no counterpart in the

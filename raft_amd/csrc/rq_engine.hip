@@ -5,6 +5,7 @@
 #include "rq_kernels.h"
 
 #include <atomic>
+#include <chrono>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -972,7 +973,19 @@ int rq_plan_destroy(rq_plan *p) {
 int rq_stream_sync(rq_engine *e, void *stream) {
     if (!e) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
-    RQ_HIP(e, hipStreamSynchronize((hipStream_t)stream));
+    // A round is tens of microseconds long and a thread blocked in
+    // hipStreamSynchronize takes 10-20 us to wake: poll for the first two
+    // milliseconds, then block.
+    const hipStream_t s = (hipStream_t)stream;
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t q;
+    while ((q = hipStreamQuery(s)) == hipErrorNotReady) {
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+            q = hipStreamSynchronize(s);
+            break;
+        }
+    }
+    RQ_HIP(e, q);
     return RQ_OK;
 }
 

@@ -314,6 +314,10 @@ class DeviceEngine:
     def _stream():
         return torch.cuda.current_stream().cuda_stream
 
+    def stream_sync(self):
+        """Host-side wait for torch's current stream through rq_stream_sync (polls first)."""
+        self._check(self._l.rq_stream_sync(self._h, self._stream()), "rq_stream_sync")
+
     def alloc(self, nbytes, kind=0):
         """Raw device memory through the C-ABI (kind: 0 default, 1 fine-grained, 2 uncached)."""
         import ctypes as C
