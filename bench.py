@@ -93,6 +93,10 @@ def parse():
                     help="summaries of this many consecutive rounds travel in one all-gather")
     ap.add_argument("--exchange-impl", choices=["auto", "native", "torch"], default="torch",
                     help="summary all-gather through librq's own RCCL communicator or torch.distributed")
+    ap.add_argument("--fence", choices=["event", "signal"], default="signal",
+                    help="how the exchange stream learns that a slot's last round is done: an event "
+                         "recorded behind the round, or the round's own completion signal "
+                         "(rq_round_desc.done_signal)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise torch.distributed and run the summary all-gather even with one rank")
     ap.add_argument("--consume", action="store_true",
@@ -315,7 +319,7 @@ def main():
         R -= 1                                   # every input set maps to one (slot, round-in-slot)
     depth = S // R
     ex = SummaryExchange(G, device, depth=depth, mode=args.summary, impl=args.exchange_impl,
-                         rounds=R) if exchange else None
+                         rounds=R, fence=args.fence) if exchange else None
     consumer = SummaryConsumer(ex) if (ex is not None and args.consume) else None
 
     # one run-long counter of groups whose commit offset left the 16-bit summary window
@@ -352,6 +356,8 @@ def main():
             kw.update(commit_lo16=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R),
                       summary_escapes=escape_counter, summary_bits=ex.bits,
                       summary_base="commit" if ex.bits < 16 else None)
+        if ex is not None and s % R == R - 1:
+            kw["done"] = ex.done_args(s // R)        # None with event fences
         sets.append(DeviceBatch(b, device, **kw))
     log_term_bits = sets[0].log_term_bits
     if args.workload == "fused":
@@ -464,6 +470,7 @@ def main():
                        "summary_impl": ex.impl if ex is not None else None,
                        "summary_consumed_on_device": consumer is not None,
                        "rounds_per_allgather": R if ex is not None else None,
+                       "exchange_fence": ex.fence if ex is not None else None,
                        "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what,
                        "ld_pad": args.ld_pad, "log_window": args.log_window, "layout": args.layout,
                        "log_term_bits": log_term_bits, "tiled": bool(getattr(sets[0], "tile_bytes", 0)),

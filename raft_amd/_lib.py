@@ -35,7 +35,8 @@ class RoundDesc(C.Structure):
                 ("commit_out", vp), ("voter_term_out", vp), ("grant_mask", vp), ("stepdown_mask", vp),
                 ("elected", vp), ("max_term", vp), ("status_out", vp), ("elected_bits", vp),
                 ("changed_bits", vp),
-                ("commit_summary", vp), ("summary_base", vp), ("summary_escapes", vp)]
+                ("commit_summary", vp), ("summary_base", vp), ("summary_escapes", vp),
+                ("done_counter", vp), ("done_signal", vp)]
 
 
 class AppendDesc(C.Structure):
@@ -88,6 +89,7 @@ PROTOTYPES = {
     "rq_plan_launch": [vp, vp],
     "rq_plan_destroy": [vp],
     "rq_stream_sync": [vp, vp],
+    "rq_stream_wait_signal": [vp, vp, vp, u64],
     "rq_comm_unique_id": [u8p],
     "rq_comm_create": [cint, u8p, cint, cint, u32, C.POINTER(vp)],
     "rq_comm_destroy": [vp],

@@ -332,6 +332,9 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     a.changed_bits = d.changed_bits;
     a.commit_lo16 = (uint16_t *)d.commit_summary; a.summary_base = (const T *)d.summary_base;
     a.summary_escapes = d.summary_escapes; a.summary_bits = sb;
+    if ((d.done_counter == nullptr) != (d.done_signal == nullptr)) return RQ_E_ARG;
+    if ((reinterpret_cast<uintptr_t>(d.done_counter) & 127) || (reinterpret_cast<uintptr_t>(d.done_signal) & 7)) return RQ_E_ARG;
+    a.done_counter = d.done_counter; a.done_signal = d.done_signal;
     return RQ_OK;
 }
 
@@ -839,9 +842,17 @@ int rq_round64(rq_engine *e, int what, uint32_t G, uint32_t m, uint32_t ld,
 }
 
 int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out) {
-    if (!e || !out || bytes == 0 || kind < 0 || kind > 2) return RQ_E_ARG;
+    if (!e || !out || bytes == 0 || kind < 0 || kind > 3) return RQ_E_ARG;
     *out = nullptr;
     RQ_HIP(e, hipSetDevice(e->device));
+    if (kind == RQ_MEM_SIGNAL) {
+        if (bytes != 8) return RQ_E_ARG;
+        hipError_t err = hipExtMallocWithFlags(out, 8, hipMallocSignalMemory);
+        if (err != hipSuccess) { e->last_hip.store((int)err); *out = nullptr; return RQ_E_NOMEM; }
+        const uint64_t zero = 0;
+        RQ_HIP(e, hipMemcpy(*out, &zero, 8, hipMemcpyHostToDevice));
+        return RQ_OK;
+    }
     const unsigned flags = kind == RQ_MEM_UNCACHED ? hipDeviceMallocUncached
                          : kind == RQ_MEM_FINEGRAINED ? hipDeviceMallocFinegrained
                                                       : hipDeviceMallocDefault;
@@ -967,6 +978,14 @@ int rq_summary_apply_dev(rq_engine *e, void *stream, const void *gathered, uint6
 int rq_plan_destroy(rq_plan *p) {
     if (!p) return RQ_E_ARG;
     delete p;
+    return RQ_OK;
+}
+
+int rq_stream_wait_signal(rq_engine *e, void *stream, const uint64_t *signal, uint64_t value) {
+    if (!e || !signal) return RQ_E_ARG;
+    RQ_HIP(e, hipSetDevice(e->device));
+    RQ_HIP(e, hipStreamWaitValue64((hipStream_t)stream, const_cast<uint64_t *>(signal), value,
+                                   hipStreamWaitValueGte, ~0ull));
     return RQ_OK;
 }
 

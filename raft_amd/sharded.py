@@ -54,15 +54,21 @@ class SummaryExchange:
     run on the communication stream while round i+1 computes into another slot.
     Every rank must use the same `groups` (pad the last shard if needed)."""
 
-    def __init__(self, groups, device, depth=2, group=None, mode="u16", impl="auto", rounds=1):
+    def __init__(self, groups, device, depth=2, group=None, mode="u16", impl="auto", rounds=1, fence="event"):
         """rounds: summaries of this many consecutive rounds share one message (one
         collective per `rounds` rounds: enqueuing an RCCL collective costs tens of
         microseconds of host time, more than a 1M-group round takes on the GPU).
         impl: "native" = librq's own RCCL communicator and side stream (one C
         call per exchange, a few microseconds of host time), "torch" =
         torch.distributed collectives, "auto" = native on a GPU when every rank
-        can create the communicator, else torch."""
-        assert mode in MODE_BITS and impl in ("auto", "native", "torch")
+        can create the communicator, else torch.
+        fence: how the side stream learns that a slot's last round has finished.
+        "event" = an event recorded on the compute stream behind the round;
+        "signal" (GPU, torch collectives) = the round itself reports its end through
+        a signal word the side stream polls (pass done_args(slot) as `done` to the
+        DeviceBatch of the slot's LAST round): no marker on the compute stream, so
+        the next round starts while this one drains."""
+        assert mode in MODE_BITS and impl in ("auto", "native", "torch") and fence in ("event", "signal")
         self.bits = MODE_BITS[mode]
         self.groups, self.mode = int(groups), mode
         self.device = torch.device(device)
@@ -93,6 +99,32 @@ class SummaryExchange:
             self._side = torch.cuda.Stream(device=self.device)
             self._done = [torch.cuda.Event() for _ in range(depth)]
             self._pending = [False] * depth
+        self.fence = fence if (self._cuda and self._comm is None) else "event"
+        self._eng = None
+        if self.fence == "signal":
+            import ctypes as C
+            from . import _lib
+            self._l = _lib.lib()
+            h = C.c_void_p()
+            rc = self._l.rq_engine_create(self.device.index or 0, 64, 1, 64, C.byref(h))
+            if rc != 0:
+                raise _lib.RqError(rc, "rq_engine_create")
+            self._eng = h
+            self._signals = []
+            for _ in range(depth):
+                p = C.c_void_p()
+                if self._l.rq_device_alloc(h, 8, 3, C.byref(p)) != 0:      # RQ_MEM_SIGNAL
+                    break
+                self._signals.append(p.value)
+            if len(self._signals) < depth:          # no signal memory on this device: event fences
+                for p in self._signals:
+                    self._l.rq_device_free(h, p)
+                self._l.rq_engine_destroy(h)
+                self._eng, self.fence = None, "event"
+        if self.fence == "signal":
+            self._counters = torch.zeros((depth, 8320 // 4), dtype=torch.int32, device=self.device)   # RQ_DONE_COUNTER_BYTES each
+            assert self._counters.data_ptr() % 128 == 0
+            self._signalled = [0] * depth          # signalled launches enqueued so far, per slot
         dt = {32: torch.int32, 16: torch.int16, 8: torch.uint8, 4: torch.int64}[self.bits]
         rb = self.round_bytes
         self._commit_views = [[t[r * rb: r * rb + self._commit_bytes].view(dt) for r in range(self.rounds)]
@@ -136,6 +168,19 @@ class SummaryExchange:
         if self._comm is not None:
             self._l.rq_comm_destroy(self._comm)
             self._comm = None
+        if self._eng is not None:
+            torch.cuda.synchronize(self.device)
+            for p in self._signals:
+                self._l.rq_device_free(self._eng, p)
+            self._l.rq_engine_destroy(self._eng)
+            self._eng = None
+
+    def done_args(self, slot):
+        """fence="signal": the (done_counter, done_signal) addresses for the launch
+        descriptor of the slot's last round; None with event fences."""
+        if self.fence != "signal":
+            return None
+        return (self._counters[slot].data_ptr(), self._signals[slot])
 
     # ---- views handed to the kernel as outputs --------------------------------
     def commit_view(self, slot, sub=0):
@@ -166,7 +211,15 @@ class SummaryExchange:
                 raise RuntimeError("rq_comm_allgather failed: %d" % rc)
             return
         if self._cuda:
-            self._side.wait_stream(torch.cuda.current_stream(self.device))
+            if self.fence == "signal":
+                # the slot's last round was enqueued with done_args(slot): wait for its count
+                self._signalled[slot] += 1
+                rc = self._l.rq_stream_wait_signal(self._eng, self._side.cuda_stream, self._signals[slot],
+                                                   self._signalled[slot])
+                if rc != 0:
+                    raise RuntimeError("rq_stream_wait_signal failed: %d" % rc)
+            else:
+                self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
                 dist.all_gather_into_tensor(self.all[slot].view(-1), self.local[slot], group=self.group)
                 self._done[slot].record(self._side)
@@ -185,7 +238,10 @@ class SummaryExchange:
             return
         if self._cuda:
             if self._pending[slot]:
-                torch.cuda.current_stream(self.device).wait_event(self._done[slot])
+                # an exchange issued several rounds ago has normally finished: the wait
+                # (a barrier packet that drains the compute stream) is only enqueued if not
+                if not self._done[slot].query():
+                    torch.cuda.current_stream(self.device).wait_event(self._done[slot])
                 self._pending[slot] = False
             return
         w = self.work[slot]
