@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""The AppendEntries consistency batch alone, for profiling: 1M groups x 4 follower
+planes (no mask), 8-bit follower-log entries, 6 rotating sets, device-resident.
+
+    python tools/append_probe.py [launches=120] [term_bits=0]
+Prints microseconds per launch and the fraction of HBM peak (186 algorithmic
+bytes per group)."""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from raft_amd import synth
+from raft_amd.device import DeviceEngine, encode_log_terms
+
+launches = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+term_bits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+G, n, dev = 1 << 20, 4, torch.device("cuda", 0)
+eng = DeviceEngine(0)
+sets = []
+for s in range(6):
+    b = synth.gen_append(G, n, seed=900 + s)
+    enc, bits, _ = encode_log_terms(b.flog_term, bits=term_bits)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    t = {k: up(b[k]) for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
+                               "match_index", "next_index")}
+    t["flog_off"] = up(b.flog_off.view(np.int32))
+    t["flog_term"] = up(enc)
+    t["follower_term_out"] = torch.zeros_like(t["follower_term"])
+    t["success_mask"] = torch.zeros(G, dtype=torch.int16, device=dev)
+    t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device=dev)
+    t["status"] = torch.zeros(G, dtype=torch.uint8, device=dev)
+    t["_bits"], t["_terms"] = bits, int(enc.size)
+    sets.append(t)
+
+
+def launch(i):
+    t = sets[i % len(sets)]
+    eng.append_check(t, G, n, G, flog_term_bits=t["_bits"], flog_terms=t["_terms"])
+
+
+for i in range(12):
+    launch(i)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for i in range(launches):
+    launch(i)
+e1.record()
+torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / launches * 1e3
+alg = 44 * 4 + 4 + 2 + 2 + 2
+print("append_check 1M x 4 followers, %d-bit entries: %.2f us per launch, %.1f %% of 8 TB/s (186 B per group)"
+      % (sets[0]["_bits"], us, 100 * alg * G / (us * 1e-6) / 8e12))
+eng.close()

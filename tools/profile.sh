@@ -6,7 +6,9 @@ TAG=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 60 --warmup 10 $*"
+# PROF_CMD overrides the profiled program (a python script path and its arguments, relative to the repository)
+if [ -n "${PROF_CMD:-}" ]; then BENCH="python3 $GRAFT_REPO_ROOT/$PROF_CMD"; else
+BENCH="python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --steps 60 --warmup 10 $*"; fi
 timeout -s KILL 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/kt.log 2>&1 || { echo "kernel-trace pass failed"; tail -5 $OUT/kt.log; exit 1; }
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
