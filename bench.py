@@ -94,9 +94,9 @@ def parse():
     ap.add_argument("--exchange-impl", choices=["auto", "native", "torch"], default="torch",
                     help="summary all-gather through librq's own RCCL communicator or torch.distributed")
     ap.add_argument("--fence", choices=["event", "signal"], default="signal",
-                    help="how the exchange stream learns that a slot's last round is done: an event "
-                         "recorded behind the round, or the round's own completion signal "
-                         "(rq_round_desc.done_signal)")
+                    help="how the exchange stream learns that a slot's rounds are done: an event recorded "
+                         "behind the last of them, or the start signal of the launch that follows "
+                         "(rq_round_desc.start_signal)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="initialise torch.distributed and run the summary all-gather even with one rank")
     ap.add_argument("--consume", action="store_true",
@@ -356,8 +356,9 @@ def main():
             kw.update(commit_lo16=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R),
                       summary_escapes=escape_counter, summary_bits=ex.bits,
                       summary_base="commit" if ex.bits < 16 else None)
-        if ex is not None and s % R == R - 1:
-            kw["done"] = ex.done_args(s // R)        # None with event fences
+        if ex is not None and s % R == 0:
+            # the first round of a slot releases the exchange of the slot before it
+            kw["start_signal"] = ex.start_signal((s // R - 1) % depth)   # None with event fences
         sets.append(DeviceBatch(b, device, **kw))
     log_term_bits = sets[0].log_term_bits
     if args.workload == "fused":
@@ -370,8 +371,12 @@ def main():
         workload = "%d groups, mixed 3-9 peers + 10%% joint consensus, Zipf log lengths" % G
     resident_mb = sum(x.bytes_resident() for x in sets) / 1e6
 
+    debug = bool(os.environ.get("RQ_BENCH_DEBUG"))
+
     def step(i):
         s = i % S
+        if debug:
+            sys.stderr.write("rank %d step %d\n" % (rank, i)); sys.stderr.flush()
         if ex is not None and s % R == 0:
             ex.begin(s // R)                 # the slot's previous all-gather must be done
         if args.what == "fused":
@@ -380,8 +385,10 @@ def main():
             eng.commit_advance(sets[s], variant=args.variant)
         else:
             eng.vote_tally(sets[s], variant=args.variant)
+        if ex is not None and s % R == 0:
+            ex.round_started((s // R - 1) % depth)
         if ex is not None and s % R == R - 1:
-            ex.exchange(s // R, async_op=True)   # R rounds of summaries in one collective
+            ex.filled(s // R)                    # R rounds of summaries in one collective
             if consumer is not None:
                 # device-side decode of the PREVIOUS exchange: its all-gather has had a whole
                 # exchange period to finish, so the compute stream does not stall on it

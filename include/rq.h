@@ -347,8 +347,7 @@ typedef struct rq_round_desc {
     void *commit_summary;       /* may be NULL */
     const void *summary_base;
     uint32_t *summary_escapes;
-    uint32_t *done_counter;     /* both NULL, or the completion signal (see below) */
-    uint64_t *done_signal;
+    uint64_t *start_signal;     /* may be NULL (see rq_stream_wait_signal) */
 } rq_round_desc;
 
 int rq_round_dev(rq_engine *e, void *stream, const rq_round_desc *d);
@@ -361,24 +360,23 @@ int rq_round_dev(rq_engine *e, void *stream, const rq_round_desc *d);
  * capture. */
 typedef struct rq_plan rq_plan;
 int rq_plan_round(rq_engine *e, const rq_round_desc *d, rq_plan **out);
-/* Completion signal of a round (rq_round_desc.done_counter / done_signal).  A
- * second stream that consumes a round's outputs -- the summary all-gather of a
- * sharded deployment -- would normally wait for an event recorded behind the
- * round; on MI355X that marker keeps the next round from starting while this
- * one drains and costs 8-13 us per dependency, a third of a 1M-group round.  With
- * done_signal set the launch reports its own end instead: when its SUMMARY
- * outputs (commit_summary, elected_bits, changed_bits -- what an exchange sends;
- * they are written through to memory) have been performed it adds one to
- * *done_signal, a 64-bit word from rq_device_alloc(e, 8, RQ_MEM_SIGNAL, ..), and
+/* Start signal (rq_round_desc.start_signal).  A second stream that consumes the
+ * outputs of the rounds enqueued so far -- the summary all-gather of a sharded
+ * deployment -- would normally wait for an event recorded behind the last of
+ * them; on MI355X that marker keeps the next round from starting while the
+ * previous one drains and costs 8-13 us per dependency, a third of a 1M-group
+ * round.  With start_signal set a launch adds one to *start_signal when it
+ * STARTS; a stream is in order, so by then every launch enqueued before it on
+ * its stream has completed and all of their outputs are visible.  The word is
+ * 64 bits from rq_device_alloc(e, 8, RQ_MEM_SIGNAL, ..) and only ever grows;
  * rq_stream_wait_signal makes `stream` wait until *signal >= value without
- * touching the round's stream.  The other outputs are ordered by the round's
- * stream as usual (an event, or the next launch on that stream).
- * done_counter is RQ_DONE_COUNTER_BYTES of zeroed ordinary device memory, 128-byte
- * aligned, that belongs to this descriptor alone (finished blocks are counted
- * there on 65 separate cache lines; the launch leaves it zero again; two launches
- * that share it must not overlap).  The signal only ever grows: the host counts the
- * signalled launches it has enqueued and waits for that count.  No counterpart
- * in the reference (its peers are in-process pointers, raft.go:26). */
+ * touching the rounds' stream.  Typical use: the first round of the next batch
+ * carries the signal that releases the exchange of the previous batch; the host
+ * counts the launches it has enqueued with a signal and waits for that count.
+ * Enqueue the signalling launch BEFORE the wait (streams may share a hardware
+ * queue).  The last batch of a run, with no launch after it, is fenced with an
+ * event as usual.  No counterpart in the reference (its peers are in-process
+ * pointers, raft.go:26). */
 int rq_stream_wait_signal(rq_engine *e, void *stream, const uint64_t *signal, uint64_t value);
 int rq_plan_launch(rq_plan *p, void *stream);
 int rq_plan_destroy(rq_plan *p);
@@ -508,7 +506,6 @@ int rq_append_check64(rq_engine *e, uint32_t G, uint32_t n, uint32_t ld,
 #define RQ_MEM_DEFAULT     0
 #define RQ_MEM_FINEGRAINED 1
 #define RQ_MEM_UNCACHED    2
-#define RQ_DONE_COUNTER_BYTES 8320   /* 65 counters, one 128-byte line each */
 #define RQ_MEM_SIGNAL      3   /* bytes must be 8: one zeroed 64-bit word a stream can wait on */
 int rq_device_alloc(rq_engine *e, uint64_t bytes, int kind, void **out);
 /* Page-locked host memory for the buffers handed to the host-buffer entry

@@ -332,9 +332,8 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     a.changed_bits = d.changed_bits;
     a.commit_lo16 = (uint16_t *)d.commit_summary; a.summary_base = (const T *)d.summary_base;
     a.summary_escapes = d.summary_escapes; a.summary_bits = sb;
-    if ((d.done_counter == nullptr) != (d.done_signal == nullptr)) return RQ_E_ARG;
-    if ((reinterpret_cast<uintptr_t>(d.done_counter) & 127) || (reinterpret_cast<uintptr_t>(d.done_signal) & 7)) return RQ_E_ARG;
-    a.done_counter = d.done_counter; a.done_signal = d.done_signal;
+    if (reinterpret_cast<uintptr_t>(d.start_signal) & 7) return RQ_E_ARG;
+    a.start_signal = d.start_signal;
     return RQ_OK;
 }
 

@@ -53,12 +53,9 @@ struct rq_round_args_t {
     const T *summary_base;         // null = 0; may be the input commit plane (offset = the round's advance)
     uint32_t *summary_escapes;     // incremented once per group that did not fit
     uint32_t summary_bits;
-    // completion signal (both null or both set): the block that finishes last adds
-    // one to *done_signal once the summary outputs of the launch have been performed;
-    // done_counter (RQ_DONE_COUNTER_BYTES, zeroed, 128-byte aligned) counts finished
-    // blocks and is left at zero again.
-    uint32_t *done_counter;
-    uint64_t *done_signal;
+    // may be null: incremented by one when the launch starts, i.e. when everything
+    // enqueued before it on its stream has completed
+    uint64_t *start_signal;
 };
 typedef rq_round_args_t<int32_t> rq_round_args;
 typedef rq_round_args_t<int64_t> rq_round64_args;

@@ -124,14 +124,6 @@ __device__ __forceinline__ void ld_u16(const uint16_t *p, int valid, uint32_t (&
     }
 }
 
-// Write-through store, performed at system scope: what the summary outputs use,
-// so that a consumer ordered only by the completion signal (signal_done below)
-// finds them in memory without any cache write-back.
-template <typename P>
-__device__ __forceinline__ void st_sys(P *p, P v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
 // ---------------------------------------------------------------------------
 // quorum index: ascending_sorted(s)[(N-1)/2] = the (N/2+1)-th largest value,
 // i.e. the largest index replicated on a strict majority of the N slots.
@@ -230,13 +222,13 @@ __device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32
                                              uint64_t *bits) {
     if constexpr (V == 1) {
         unsigned long long w = __ballot(field & 1u);
-        if ((threadIdx.x & 63) == 0 && g0 < G) st_sys(bits + (g0 >> 6), (uint64_t)w);
+        if ((threadIdx.x & 63) == 0 && g0 < G) bits[g0 >> 6] = w;
     } else {
         constexpr int lanes_per_word = 64 / V;
         unsigned long long w = (unsigned long long)field << (g0 & 63);
 #pragma unroll
         for (int o = lanes_per_word / 2; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
-        if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) st_sys(bits + (g0 >> 6), (uint64_t)w);
+        if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) bits[g0 >> 6] = w;
     }
 }
 
@@ -303,12 +295,8 @@ __device__ __forceinline__ uint32_t store_commit_summary(const rq_round_args_t<T
         escapes += (!fit && k < valid) ? 1u : 0u;
         nibbles |= (k < valid ? lo[k] : 0u) << (4 * k);
     }
-#pragma unroll
-    for (int k = 0; k < V; k++) {
-        if (k >= valid) break;
-        if (bits == 16) st_sys(a.commit_lo16 + g0 + k, (uint16_t)lo[k]);
-        else if (bits == 8) st_sys(reinterpret_cast<uint8_t *>(a.commit_lo16) + g0 + k, (uint8_t)lo[k]);
-    }
+    if (bits == 16) st_u16<V, NTS, FULL>(a.commit_lo16 + g0, valid, lo);
+    else if (bits == 8) st_u8<V, NTS, FULL>(reinterpret_cast<uint8_t *>(a.commit_lo16) + g0, valid, lo);
     escapes_out = escapes;      // summed over the wave by count_escapes(): one atomic per wave
     return nibbles;
 }
@@ -339,7 +327,7 @@ __device__ __forceinline__ void pack_nibbles(uint32_t field, uint64_t g0, uint32
     unsigned long long w = (unsigned long long)field << (4 * (g0 & 15));
 #pragma unroll
     for (int o = lanes_per_word / 2; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
-    if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) st_sys(words + (g0 >> 4), (uint64_t)w);
+    if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) words[g0 >> 4] = w;
 }
 
 // What a round body hands back to the kernel for the wave-level packing.
@@ -386,46 +374,23 @@ __device__ __forceinline__ P *at(P *base, const group_addr &ga, uint32_t p = 0) 
 }
 
 // ---------------------------------------------------------------------------
-// Completion signal.  A stream that consumes a round's outputs (the summary
-// all-gather of a sharded deployment) normally waits for an event recorded
-// behind the round; that marker keeps the next round from starting while this
-// one drains, and costs more than the dependency is worth when a round is
-// 26 us long.  Instead the launch itself reports its end: every block, once
-// its stores have been performed, bumps done_counter; the block that sees the
-// count complete adds one to done_signal, which the consumer's stream polls
-// (rq_stream_wait_signal).  The signal covers the SUMMARY outputs (commit
-// summary, elected_bits, changed_bits): they are written through to memory
-// (st_sys), each wave waits for its stores before the block's barrier, so no
-// cache write-back is needed -- a release fence per block would write the L2
-// back 8192 times per launch (measured: 550 us instead of 26).  The other
-// outputs stay ordered by the stream as usual.  Must be reached by every
-// thread of the block.
+// Start signal.  A stream that consumes the outputs of the rounds enqueued so
+// far (the summary all-gather of a sharded deployment) normally waits for an
+// event recorded behind the last of them; that marker keeps the next round from
+// starting while the previous one drains and costs 8-13 us per dependency when
+// a round is 26 us long.  Instead the NEXT launch on the compute stream reports
+// that it has started -- which, a stream being in order, means every earlier
+// launch on it has completed and its outputs are visible -- by adding one to
+// start_signal, a word the consumer's stream polls (rq_stream_wait_signal).
+// One atomic by one thread: nothing is added to the stream but kernels.
+// (Reporting the END of a launch from inside it was built first and rejected:
+// a release fence per block wrote the L2 back 8192 times, 550 us per launch;
+// counting blocks with write-through outputs instead still cost 4.5 us.)
 // ---------------------------------------------------------------------------
-// Counting is two-level: atomics on one address are performed one after the
-// other, ~10 ns each across the XCDs (8192 blocks on one word: 78 us), so block b
-// counts on word b % kDoneFan, each word a cache line of its own, and the block
-// that completes a word counts it on the top word: 128 + 64 serial steps instead
-// of 8192.
-constexpr uint32_t kDoneFan = 64;
-constexpr uint32_t kDoneStride = 32;     // uint32 words: one 128-byte line per counter
 template <typename T>
-__device__ __forceinline__ void signal_done(const rq_round_args_t<T> &a) {
-    if (!a.done_signal) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores have been performed
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const uint32_t blocks = gridDim.x, c = blockIdx.x % kDoneFan;
-        const uint32_t mine = (blocks - c + kDoneFan - 1) / kDoneFan;        // blocks that count on word c
-        uint32_t *sub = a.done_counter + (size_t)(1 + c) * kDoneStride;
-        if (__hip_atomic_fetch_add(sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine - 1) {
-            __hip_atomic_store(sub, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t words = blocks < kDoneFan ? blocks : kDoneFan;    // words that any block counts on
-            if (__hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == words - 1) {
-                __hip_atomic_store(a.done_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_fetch_add(a.done_signal, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
-    }
+__device__ __forceinline__ void signal_started(const rq_round_args_t<T> &a) {
+    if (a.start_signal && blockIdx.x == 0 && threadIdx.x == 0)
+        __hip_atomic_fetch_add(a.start_signal, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------
@@ -561,6 +526,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 
 template <int N, int V, int WHAT, bool NT, bool NTG, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
+    signal_started(a);
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     round_fields f{0, 0, 0, 0};
     if (g0 + V <= a.G)
@@ -576,7 +542,6 @@ __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
             pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));
         if (a.commit_lo16 && a.summary_escapes) count_escapes(f.escapes, a.summary_escapes);
     }
-    signal_done(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -847,6 +812,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
 
 template <int MMAX, int V, int WHAT, bool NT, bool NTG, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
+    signal_started(a);
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     round_fields f;
     // Every lane runs a body: the wave-wide ballots inside need all of them.
@@ -866,7 +832,6 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
             pack_nibbles<V>(f.nibbles, g0, a.G, reinterpret_cast<uint64_t *>(a.commit_lo16));
         if (a.commit_lo16 && a.summary_escapes) count_escapes(f.escapes, a.summary_escapes);
     }
-    signal_done(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -940,8 +905,7 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if (args.commit_lo16 && args.summary_bits == 4 && !aligned_to(args.commit_lo16, 8)) return hipErrorInvalidValue;
     const uint32_t tb = args.log_term_bits;
     if ((what & RQ_WHAT_COMMIT) && tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
-    if ((args.done_signal == nullptr) != (args.done_counter == nullptr)) return hipErrorInvalidValue;
-    if (!aligned_to(args.done_signal, 8) || !aligned_to(args.done_counter, 128)) return hipErrorInvalidValue;
+    if (!aligned_to(args.start_signal, 8)) return hipErrorInvalidValue;
     if (variant & ~(RQ_VAR_PLAIN | 0xF00)) return hipErrorInvalidValue;
     const int bsel = (variant >> 8) & 0xF;
     if (bsel > 4) return hipErrorInvalidValue;

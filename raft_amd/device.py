@@ -84,7 +84,7 @@ class DeviceBatch:
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
                  share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None,
-                 summary_bits=16, log_term_bits=None, log_term_base=False, tiled=False, done=None):
+                 summary_bits=16, log_term_bits=None, log_term_base=False, tiled=False, start_signal=None):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         share_log_with: another DeviceBatch whose log_off/log_term device arrays
@@ -101,9 +101,9 @@ class DeviceBatch:
         tiled=True keeps every per-group and per-slot array, inputs and outputs, in
         ONE block of 64-group tiles (rq_round_desc.tile_bytes) instead of separate
         slot-major planes; the log arena and the bit summaries stay plain arrays.
-        done: (done_counter, done_signal) device addresses -- the round then reports
-        its own completion through the signal word (rq_stream_wait_signal)."""
-        self.done = done
+        start_signal: device address of a signal word the launch bumps when it starts
+        (everything enqueued before it on its stream has completed by then)."""
+        self.start_signal = start_signal
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
         G, n, ld = self.G, self.n, self.ld
@@ -370,8 +370,7 @@ class DeviceEngine:
             d.elected_bits = p(o["elected_bits"]) if want_bits else None
         d.status_out = p(o["status"]) if status else None
         d.changed_bits = p(o.get("changed_bits"))
-        if b.done is not None:
-            d.done_counter, d.done_signal = b.done
+        d.start_signal = b.start_signal
         return d
 
     def round(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):

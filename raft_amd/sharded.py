@@ -62,12 +62,17 @@ class SummaryExchange:
         call per exchange, a few microseconds of host time), "torch" =
         torch.distributed collectives, "auto" = native on a GPU when every rank
         can create the communicator, else torch.
-        fence: how the side stream learns that a slot's last round has finished.
-        "event" = an event recorded on the compute stream behind the round;
-        "signal" (GPU, torch collectives) = the round itself reports its end through
-        a signal word the side stream polls (pass done_args(slot) as `done` to the
-        DeviceBatch of the slot's LAST round): no marker on the compute stream, so
-        the next round starts while this one drains."""
+        fence: how the side stream learns that a slot's rounds have finished.
+        "event" = an event recorded on the compute stream behind the last round;
+        "signal" (GPU, torch collectives) = the NEXT launch on the compute stream
+        reports that it has started, which in an in-order stream means the slot's
+        rounds are complete, through a signal word the side stream polls: no marker
+        on the compute stream, so the next round starts while the last one drains.
+        Protocol with signal fences: the launch that follows a slot's last round
+        carries start_signal(slot) in its descriptor; call filled(slot) after the
+        slot's last round has been enqueued and round_started(slot) after EVERY
+        launch that carries start_signal(slot) (the host counts them); flush() /
+        wait_all() fence whatever is still pending with an event."""
         assert mode in MODE_BITS and impl in ("auto", "native", "torch") and fence in ("event", "signal")
         self.bits = MODE_BITS[mode]
         self.groups, self.mode = int(groups), mode
@@ -89,6 +94,7 @@ class SummaryExchange:
         # call on this stack, a blocking call on a side stream ~12 us, and the round
         # itself is only ~30 us.
         self._cuda = self.device.type == "cuda"
+        self._gloo = dist.is_initialized() and dist.get_backend(group) == "gloo"
         self._comm = None
         if self._cuda and impl != "torch" and dist.is_initialized():
             self._comm = self._native_comm(depth)
@@ -122,9 +128,8 @@ class SummaryExchange:
                 self._l.rq_engine_destroy(h)
                 self._eng, self.fence = None, "event"
         if self.fence == "signal":
-            self._counters = torch.zeros((depth, 8320 // 4), dtype=torch.int32, device=self.device)   # RQ_DONE_COUNTER_BYTES each
-            assert self._counters.data_ptr() % 128 == 0
-            self._signalled = [0] * depth          # signalled launches enqueued so far, per slot
+            self._launched = [0] * depth           # launches enqueued so far that carry the slot's signal
+        self._filled = [False] * depth             # the slot's rounds are enqueued, its exchange is not
         dt = {32: torch.int32, 16: torch.int16, 8: torch.uint8, 4: torch.int64}[self.bits]
         rb = self.round_bytes
         self._commit_views = [[t[r * rb: r * rb + self._commit_bytes].view(dt) for r in range(self.rounds)]
@@ -175,12 +180,36 @@ class SummaryExchange:
             self._l.rq_engine_destroy(self._eng)
             self._eng = None
 
-    def done_args(self, slot):
-        """fence="signal": the (done_counter, done_signal) addresses for the launch
-        descriptor of the slot's last round; None with event fences."""
+    def start_signal(self, slot):
+        """fence="signal": address of the slot's signal word, for the descriptor of the
+        launch that follows the slot's last round; None with event fences."""
+        return self._signals[slot] if self.fence == "signal" else None
+
+    def filled(self, slot):
+        """The slot's last round has been enqueued on the current stream.  Event
+        fences: the exchange is issued now.  Signal fences: it is issued by the
+        round_started(slot) that follows."""
+        if self.fence == "signal":
+            self._filled[slot] = True
+        else:
+            self.exchange(slot)
+
+    def round_started(self, slot):
+        """A launch carrying start_signal(slot) has just been enqueued."""
         if self.fence != "signal":
-            return None
-        return (self._counters[slot].data_ptr(), self._signals[slot])
+            return
+        self._launched[slot] += 1
+        if self._filled[slot]:
+            self._filled[slot] = False
+            self.exchange(slot, _after_signal=self._launched[slot])
+
+    def flush(self):
+        """Issue the exchange of every slot that is filled and still waits for a
+        following launch (the end of a run), fenced with an event."""
+        for slot, f in enumerate(self._filled):
+            if f:
+                self._filled[slot] = False
+                self.exchange(slot)
 
     # ---- views handed to the kernel as outputs --------------------------------
     def commit_view(self, slot, sub=0):
@@ -197,7 +226,7 @@ class SummaryExchange:
         self.wait(slot)
 
     # ---- the collective ------------------------------------------------------------
-    def exchange(self, slot, async_op=True):
+    def exchange(self, slot, async_op=True, _after_signal=None):
         """All-gather slot's summary, ordered after the work already enqueued on
         the current stream (the round that produced it), without blocking that
         stream: later rounds overlap with the collective."""
@@ -211,17 +240,25 @@ class SummaryExchange:
                 raise RuntimeError("rq_comm_allgather failed: %d" % rc)
             return
         if self._cuda:
-            if self.fence == "signal":
-                # the slot's last round was enqueued with done_args(slot): wait for its count
-                self._signalled[slot] += 1
+            if _after_signal is not None:
+                # a launch enqueued after the slot's rounds bumps the word when it starts
                 rc = self._l.rq_stream_wait_signal(self._eng, self._side.cuda_stream, self._signals[slot],
-                                                   self._signalled[slot])
+                                                   _after_signal)
                 if rc != 0:
                     raise RuntimeError("rq_stream_wait_signal failed: %d" % rc)
             else:
                 self._side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(self._side):
-                dist.all_gather_into_tensor(self.all[slot].view(-1), self.local[slot], group=self.group)
+                if self._gloo:
+                    # rehearsal on a GPU with the CPU backend: the message is staged through the
+                    # host here (torch's gloo backend would stage device tensors through pool
+                    # streams and worker threads of its own)
+                    host = self.local[slot].to("cpu")          # blocks until the side stream has the message
+                    out = torch.empty((self.world, self.nbytes), dtype=torch.uint8)
+                    dist.all_gather_into_tensor(out.view(-1), host, group=self.group)
+                    self.all[slot].copy_(out)
+                else:
+                    dist.all_gather_into_tensor(self.all[slot].view(-1), self.local[slot], group=self.group)
                 self._done[slot].record(self._side)
             self._pending[slot] = True
             return
@@ -231,6 +268,9 @@ class SummaryExchange:
 
     def wait(self, slot):
         """Order the current stream (for gloo: the host) after slot's exchange."""
+        if self._filled[slot]:                 # nothing was launched after the slot's rounds: event fence
+            self._filled[slot] = False
+            self.exchange(slot)
         if self._comm is not None:
             rc = self._l.rq_comm_wait(self._comm, torch.cuda.current_stream(self.device).cuda_stream, slot)
             if rc != 0:

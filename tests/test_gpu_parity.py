@@ -1312,11 +1312,12 @@ def test_tiled_layout(dev, kind):
 
 
 @pytest.mark.parametrize("kind", ["fixed", "joint", "wide"])
-def test_round_completion_signal(dev, kind):
-    """rq_round_desc.done_signal: the launch itself reports its end, a second stream
-    waits for the count with rq_stream_wait_signal and then reads the summary
-    outputs (the ones the signal covers); no event is recorded on the round's
-    stream.  The word grows by one per launch and the block counter is left at zero."""
+def test_round_start_signal(dev, kind):
+    """rq_round_desc.start_signal: a launch bumps the word when it starts, i.e. when
+    the launches enqueued before it on its stream are complete; a second stream waits
+    for the count with rq_stream_wait_signal and then reads the EARLIER launch's
+    outputs.  No event is recorded on the rounds' stream; the word grows by one per
+    signalling launch."""
     import ctypes as C
     import time
     import torch
@@ -1325,7 +1326,6 @@ def test_round_completion_signal(dev, kind):
     sig = C.c_void_p()
     assert l.rq_device_alloc(h, 8, 3, C.byref(sig)) == 0
     assert l.rq_device_alloc(h, 16, 3, C.byref(C.c_void_p())) == -1          # a signal is one 8-byte word
-    counter = torch.zeros(8320 // 4, dtype=torch.int32, device="cuda:0")      # RQ_DONE_COUNTER_BYTES
     if kind == "fixed":
         b = synth.gen_fused(65536 + 17, 5, seed=71)
         exp = o.fused_round(*b.fused_args())
@@ -1335,46 +1335,44 @@ def test_round_completion_signal(dev, kind):
     else:
         b, _ = synth.widen(synth.gen_fused(40000, 5, seed=73), index_shift=0, term_shift=1 << 40, id_shift=1 << 41, seed=5)
         exp = o.round64(3, *b.fused_args())
-    G = int(b["G"])
-    summary = torch.zeros(G, dtype=torch.uint8, device="cuda:0")
-    db = DeviceBatch(b, tiled=(kind == "fixed"), done=(counter.data_ptr(), sig.value), commit_lo16=summary,
-                     summary_escapes=torch.zeros(2, dtype=torch.int32, device="cuda:0"), summary_bits=8,
-                     summary_base="commit")
-    adv = np.asarray(exp["commit"]).astype(np.int64) - np.asarray(b["commit"]).astype(np.int64)
-    exp_summary = np.where((adv >= 0) & (adv < 255), adv, 255).astype(np.uint8)
-    exp_bits = np.packbits(np.asarray(exp["elected"]).astype(np.uint8), bitorder="little")
+    first = DeviceBatch(b)                                     # the launch whose outputs are consumed
+    follower = DeviceBatch(b, tiled=(kind == "fixed"), start_signal=sig.value)   # the launch after it
     side = torch.cuda.Stream()
-    bits = db.o["elected_bits"]
-    copy_s, copy_b = torch.zeros_like(summary), torch.zeros_like(bits)
+    names = ("commit_out", "elected", "max_term", "status", "grant_mask")
+    copies = {k: torch.zeros_like(first.o[k]) for k in names}
     value = np.zeros(1, np.uint64)
     try:
         for k in range(1, 4):
-            summary.fill_(77); bits.fill_(-1); copy_s.zero_(); copy_b.zero_()
+            for n_ in names:
+                first.o[n_].fill_(99)
+                copies[n_].zero_()
             torch.cuda.synchronize()
-            dev.fused_round(db)
+            dev.fused_round(first)
+            dev.fused_round(follower)                          # enqueued BEFORE the wait on the other stream
             assert l.rq_stream_wait_signal(h, side.cuda_stream, sig.value, k) == 0
-            with torch.cuda.stream(side):                      # ordered behind the round by the signal alone
-                copy_s.copy_(summary, non_blocking=True)
-                copy_b.copy_(bits, non_blocking=True)
+            with torch.cuda.stream(side):                      # ordered behind `first` by the signal alone
+                for n_ in names:
+                    copies[n_].copy_(first.o[n_], non_blocking=True)
             t0 = time.time()
             while not side.query():
-                assert time.time() - t0 < 20, "the completion signal never arrived"
+                assert time.time() - t0 < 20, "the start signal never arrived"
                 time.sleep(0.001)
-            got_s = copy_s.cpu().numpy()
-            got_b = copy_b.cpu().numpy().view(np.uint8)[: exp_bits.size]
-            assert np.array_equal(got_s, exp_summary) and np.array_equal(got_b, exp_bits), k
+            assert np.array_equal(copies["commit_out"].cpu().numpy(), exp["commit"]), k
+            assert np.array_equal(copies["elected"].cpu().numpy(), exp["elected"]), k
+            assert np.array_equal(copies["max_term"].cpu().numpy(), exp["max_term"]), k
+            assert np.array_equal(copies["status"].cpu().numpy(), exp["status"]), k
+            assert np.array_equal(copies["grant_mask"].cpu().numpy().view(np.uint16), exp["grant_mask"]), k
             torch.cuda.synchronize()
             dev.download(sig.value, value)
-            assert int(value[0]) == k and int(counter.abs().sum().item()) == 0
-        got = db.results()
+            assert int(value[0]) == k
+        got = follower.results()                               # the signalling launch computes the same round
         assert np.array_equal(got["commit"], exp["commit"]) and np.array_equal(got["elected"], exp["elected"])
-        assert np.array_equal(got["max_term"], exp["max_term"]) and np.array_equal(got["status"], exp["status"])
     finally:
         value[0] = 1 << 40                                     # releases a waiter whatever went wrong
         dev.upload(sig.value, value)
         torch.cuda.synchronize()
         dev.free(sig.value)
-    # one of the two words alone is an argument error
-    db2 = DeviceBatch(synth.gen_fused(100, 3, seed=1), done=(counter.data_ptr(), None))
+    # a misaligned signal word is an argument error
+    bad = DeviceBatch(synth.gen_fused(100, 3, seed=1), start_signal=first.o["elected"].data_ptr() + 4)
     with pytest.raises(Exception):
-        dev.fused_round(db2)
+        dev.fused_round(bad)
