@@ -226,7 +226,43 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     ms = timed_launches(torch, device, lambda i: eng.fused_round(sets[i % S]), steps, warmup, S)
     out["planes"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n), ms), input_sets=S,
                          note="slot-major planes field[p * ld + g] instead of 64-group tiles")
+    # the two decisions as separate launches (the headline's sets in planes)
+    ms = timed_launches(torch, device, lambda i: eng.commit_advance(sets[i % S]), steps, warmup, S)
+    out["commit_only"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n, "commit"), ms),
+                              alg_bytes_per_group=alg_bytes_per_group(n, "commit"))
+    ms = timed_launches(torch, device, lambda i: eng.vote_tally(sets[i % S]), steps, warmup, S)
+    out["vote_only"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n, "vote"), ms),
+                            alg_bytes_per_group=alg_bytes_per_group(n, "vote"))
     del sets
+    torch.cuda.empty_cache()
+
+    # AppendEntries consistency batch (raft.go:142-153) + leader bookkeeping: n - 1 follower planes,
+    # follower logs in the narrowest entries their terms fit
+    from raft_amd.device import encode_log_terms
+    asets = []
+    for s in range(6):
+        ab = synth.gen_append(G, n - 1, seed=900 + s)
+        enc, bits, _ = encode_log_terms(ab.flog_term, bits=0)
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        t = {k: up(ab[k]) for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
+                                    "match_index", "next_index")}
+        t["flog_off"] = up(ab.flog_off.view(np.int32))
+        t["flog_term"] = up(enc)
+        t["follower_term_out"] = torch.zeros_like(t["follower_term"])
+        t["success_mask"] = torch.zeros(G, dtype=torch.int16, device=device)
+        t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device=device)
+        t["status"] = torch.zeros(G, dtype=torch.uint8, device=device)
+        t["_bits"], t["_terms"] = bits, int(enc.size)
+        asets.append(t)
+    A = len(asets)
+    ms = timed_launches(torch, device, lambda i: eng.append_check(
+        asets[i % A], G, n - 1, G, flog_term_bits=asets[i % A]["_bits"], flog_terms=asets[i % A]["_terms"]),
+        steps, warmup, A)
+    abytes = 44 * (n - 1) + 4 + 2 + 2 + 2
+    out["append_check"] = dict(kernel_ms=ms, frac=frac(abytes, ms), input_sets=A, alg_bytes_per_group=abytes,
+                               note="AppendEntries consistency batch, %d follower planes, %d-bit follower-log entries"
+                                    % (n - 1, asets[0]["_bits"]))
+    del asets
     torch.cuda.empty_cache()
 
     # wide layout on the first sets (8 output sets x 66 MB exceed the Infinity Cache)
