@@ -931,6 +931,40 @@ def test_sharded_exchange_one_rank_on_gpu(dev):
                 assert np.array_equal(np.unpackbits(bits, bitorder="little")[:G], exps[i].elected)
             assert int(esc[0]) == 0
             ex.close()
+        # start-signal fences: the first round of the next slot releases the exchange of the
+        # slot before it; several passes over three slots with fresh inputs each time, the
+        # gathered bytes of every pass are those of that pass (nothing stale, nothing early)
+        depth, R, G = 3, 2, 70001
+        ex = SummaryExchange(G, device, depth=depth, mode="u8", impl="torch", rounds=R, fence="signal")
+        assert ex.fence == "signal"
+        esc = torch.zeros(2, dtype=torch.int32, device=device)
+        host = [[synth.gen_fused(G, 5, seed=500 + 10 * p + i) for i in range(depth * R)] for p in range(3)]
+        sets = [[DeviceBatch(host[p][i], tiled=True, commit_lo16=ex.commit_view(i // R, i % R),
+                             elected_bits=ex.bits_view(i // R, i % R), summary_escapes=esc, summary_bits=8,
+                             summary_base="commit",
+                             start_signal=ex.start_signal((i // R - 1) % depth) if i % R == 0 else None)
+                 for i in range(depth * R)] for p in range(3)]
+        for p in range(3):
+            for i, db in enumerate(sets[p]):
+                slot, sub = i // R, i % R
+                if sub == 0:
+                    ex.begin(slot)
+                dev.fused_round(db)
+                if sub == 0:
+                    ex.round_started((slot - 1) % depth)
+                if sub == R - 1:
+                    ex.filled(slot)
+            ex.wait_all()                                    # the last slot has no launch after it: event fence
+            torch.cuda.synchronize()
+            for i in range(depth * R):
+                slot, sub = i // R, i % R
+                b = host[p][i]
+                e = o.fused_round(*b.fused_args())
+                adv = (e.commit.astype(np.int64) - b.commit.astype(np.int64)).astype(np.int32)
+                assert np.array_equal(ex.gathered_commit(slot, sub).cpu().numpy().reshape(-1), adv), (p, i)
+                bits = ex.gathered_bits(slot, sub).cpu().numpy().view(np.uint8)
+                assert np.array_equal(np.unpackbits(bits, bitorder="little")[:G], e.elected), (p, i)
+        ex.close()
     finally:
         dist.destroy_process_group()
 
