@@ -17,7 +17,7 @@ raft_amd/librq.so: build/rq_kernels.o build/rq_kernels64.o build/rq_engine.o bui
 
 HOST = $(CSRC)/host
 raft_amd/libraft_host.so: $(HOST)/raft_host.cpp $(HOST)/raft_host_resident.cpp $(HOST)/raft_host_capi.cpp $(HOST)/raft_host.hpp include/rq.h raft_amd/librq.so
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -Wextra $(HOST)/raft_host.cpp $(HOST)/raft_host_resident.cpp $(HOST)/raft_host_capi.cpp \
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Wextra -pthread $(HOST)/raft_host.cpp $(HOST)/raft_host_resident.cpp $(HOST)/raft_host_capi.cpp \
 	    -Lraft_amd -lrq -Wl,-rpath,'$$ORIGIN' -o $@
 
 oracle/librq_oracle.so: oracle/raft_oracle.c oracle/raft_oracle.h

@@ -1,7 +1,9 @@
 // raft_host.cpp -- see raft_host.hpp.
 #include "raft_host.hpp"
 
+#include <atomic>
 #include <climits>
+#include <thread>
 
 #include "../../../include/rq.h"
 
@@ -91,6 +93,24 @@ void Node::SeedLogForTest(const std::vector<int64_t> &terms) {
 
 // ---- batched driver ---------------------------------------------------------
 
+uint32_t ParallelWorkers(uint32_t groups) {
+    if (groups < 32768) return 1;
+    const uint32_t hw = std::thread::hardware_concurrency();
+    const uint32_t t = hw ? hw : 1;
+    return t > 16 ? 16 : t;
+}
+
+void ParallelOverGroups(uint32_t groups, const std::function<void(uint32_t, uint32_t, uint32_t)> &fn) {
+    const uint32_t workers = ParallelWorkers(groups);
+    if (workers <= 1) { fn(0, groups, 0); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(workers - 1);
+    auto bound = [&](uint32_t w) { return (uint32_t)((uint64_t)groups * w / workers); };
+    for (uint32_t w = 1; w < workers; w++) pool.emplace_back(fn, bound(w), bound(w + 1), w);
+    fn(0, bound(1), 0);
+    for (std::thread &t : pool) t.join();
+}
+
 // The lowest value of each layout is its empty-log marker and cannot be a value.
 static bool narrow(int64_t v, int32_t &out) {
     if (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX) return false;
@@ -114,75 +134,104 @@ template <typename T>
 int BatchedDriver::FlattenT(const std::vector<Group> &groups, uint32_t n, RoundBuffersT<T> &b) {
     typedef layout_limits<T> lim;
     const uint32_t G = (uint32_t)groups.size();
-    b = RoundBuffersT<T>();
-    b.groups = G; b.slots = n; b.ld = G;
+    if (n < 1 || n > RQ_MAX_SLOTS) return kDriverShape;
+    b.groups = G; b.slots = n; b.ld = G; b.mixed = false;
     const size_t plane = (size_t)n * G;
-    b.match.assign(plane, 0); b.voterTerm.assign(plane, 0); b.votedFor.assign(plane, -1);
-    b.lastLogTerm.assign(plane, lim::kLogEmpty); b.voterTermOut.assign(plane, 0);
-    b.commit.assign(G, lim::kMax);          // no leader: N > commit is never true
-    b.leaderTerm.assign(G, 0);
-    b.candTerm.assign(G, lim::kBelowAll);   // no candidate: no voter's term moves, results are not applied
-    b.candId.assign(G, -1);
-    b.commitOut.assign(G, 0); b.maxTerm.assign(G, 0);
-    b.grantMask.assign(G, 0); b.stepdownMask.assign(G, 0);
-    b.elected.assign(G, 0); b.status.assign(G, 0);
-    b.logOff.assign((size_t)G + 1, 0);
-    b.memberMask.assign(G, 0);
+    // sizes only: every element is written below (a buffer kept from the last call is reused as it is)
+    b.match.resize(plane); b.voterTerm.resize(plane); b.votedFor.resize(plane);
+    b.lastLogTerm.resize(plane); b.voterTermOut.resize(plane);
+    b.commit.resize(G); b.leaderTerm.resize(G); b.candTerm.resize(G); b.candId.resize(G);
+    b.commitOut.resize(G); b.maxTerm.resize(G); b.grantMask.resize(G); b.stepdownMask.resize(G);
+    b.elected.resize(G); b.status.resize(G); b.memberMask.resize(G);
+    b.logOff.resize((size_t)G + 1);
+    // pass 1: the leaders' log lengths, then their offsets in the arena
+    std::atomic<int> err{kDriverOk};
+    ParallelOverGroups(G, [&](uint32_t g0, uint32_t g1, uint32_t) {
+        for (uint32_t g = g0; g < g1; g++) {
+            const Group &grp = groups[g];
+            const size_t k = grp.Members.size();
+            if (k < 1 || k > n) { err.store(kDriverShape); return; }
+            b.logOff[g + 1] = grp.Leader ? (uint32_t)grp.Leader->log.size() : 0u;
+            if (grp.Leader && grp.Leader->log.size() > 0xFFFFFFFFull) { err.store(kDriverRange); return; }
+        }
+    });
+    if (err.load() != kDriverOk) return err.load();
+    uint64_t total = 0;
+    b.logOff[0] = 0;
     for (uint32_t g = 0; g < G; g++) {
-        const Group &grp = groups[g];
-        const uint32_t k = (uint32_t)grp.Members.size();
-        if (k < 1 || k > n || n > RQ_MAX_SLOTS) return kDriverShape;
-        b.memberMask[g] = (uint16_t)((1u << k) - 1u);
-        if (k != n) b.mixed = true;
-        if (const Node *l = grp.Leader) {
-            if (!narrow(l->commitIndex, b.commit[g]) || !narrow(l->currentTerm, b.leaderTerm[g])) return kDriverRange;
-            for (uint32_t p = 0; p < k && p < l->matchIndex.size(); p++)
-                if (!narrow(l->matchIndex[p], b.match[(size_t)p * G + g])) return kDriverRange;
-            for (const Entry &e : l->log) {
-                T t;
-                if (!narrow(e.TermNum, t)) return kDriverRange;
-                b.logTerm.push_back(t);
-            }
-        }
-        if (b.logTerm.size() > 0xFFFFFFFFull) return kDriverRange;
-        b.logOff[g + 1] = (uint32_t)b.logTerm.size();
-        if (const Node *c = grp.Candidate) {
-            if (!narrow(c->currentTerm, b.candTerm[g]) || !narrow(c->id, b.candId[g])) return kDriverRange;
-        }
-        for (uint32_t p = 0; p < k; p++) {
-            const Node *m = grp.Members[p];
-            const size_t i = (size_t)p * G + g;
-            if (!narrow(m->currentTerm, b.voterTerm[i]) || !narrow(m->votedFor, b.votedFor[i])) return kDriverRange;
-            if (!m->log.empty()) {
-                if (!narrow(m->log.back().TermNum, b.lastLogTerm[i]) || b.lastLogTerm[i] == lim::kLogEmpty)
-                    return kDriverRange;
-            }
-        }
+        total += b.logOff[g + 1];
+        if (total > 0xFFFFFFFFull) return kDriverRange;
+        b.logOff[g + 1] = (uint32_t)total;
     }
-    if (b.logTerm.empty()) b.logTerm.push_back(0);
+    b.logTerm.resize(total ? (size_t)total : 1);
+    if (!total) b.logTerm[0] = 0;
+    // pass 2: every group's slots, defaults included
+    std::atomic<bool> mixed{false};
+    ParallelOverGroups(G, [&](uint32_t g0, uint32_t g1, uint32_t) {
+        bool any_small = false;
+        for (uint32_t g = g0; g < g1; g++) {
+            const Group &grp = groups[g];
+            const uint32_t k = (uint32_t)grp.Members.size();
+            b.memberMask[g] = (uint16_t)((1u << k) - 1u);
+            any_small |= k != n;
+            b.commit[g] = lim::kMax;            // no leader: N > commit is never true
+            b.leaderTerm[g] = 0;
+            b.candTerm[g] = lim::kBelowAll;     // no candidate: no voter's term moves, results are not applied
+            b.candId[g] = -1;
+            b.commitOut[g] = 0; b.maxTerm[g] = 0; b.grantMask[g] = 0; b.stepdownMask[g] = 0;
+            b.elected[g] = 0; b.status[g] = 0;
+            for (uint32_t p = 0; p < n; p++) {
+                const size_t i = (size_t)p * G + g;
+                b.match[i] = 0; b.voterTerm[i] = 0; b.votedFor[i] = -1;
+                b.lastLogTerm[i] = lim::kLogEmpty; b.voterTermOut[i] = 0;
+            }
+            bool ok = true;
+            if (const Node *l = grp.Leader) {
+                ok = ok && narrow(l->commitIndex, b.commit[g]) && narrow(l->currentTerm, b.leaderTerm[g]);
+                for (uint32_t p = 0; p < k && p < l->matchIndex.size(); p++)
+                    ok = ok && narrow(l->matchIndex[p], b.match[(size_t)p * G + g]);
+                T *dst = b.logTerm.data() + b.logOff[g];
+                for (size_t e = 0; e < l->log.size(); e++) ok = ok && narrow(l->log[e].TermNum, dst[e]);
+            }
+            if (const Node *c = grp.Candidate)
+                ok = ok && narrow(c->currentTerm, b.candTerm[g]) && narrow(c->id, b.candId[g]);
+            for (uint32_t p = 0; p < k; p++) {
+                const Node *m = grp.Members[p];
+                const size_t i = (size_t)p * G + g;
+                ok = ok && narrow(m->currentTerm, b.voterTerm[i]) && narrow(m->votedFor, b.votedFor[i]);
+                if (!m->log.empty())
+                    ok = ok && narrow(m->log.back().TermNum, b.lastLogTerm[i]) && b.lastLogTerm[i] != lim::kLogEmpty;
+            }
+            if (!ok) { err.store(kDriverRange); return; }
+        }
+        if (any_small) mixed.store(true);
+    });
+    if (err.load() != kDriverOk) return err.load();
+    b.mixed = mixed.load();
     return kDriverOk;
 }
 
 template <typename T>
 void BatchedDriver::ApplyT(std::vector<Group> &groups, const RoundBuffersT<T> &b) {
-    const uint32_t G = b.groups;
-    for (uint32_t g = 0; g < G; g++) {
-        Group &grp = groups[g];
-        Node *leader_before = grp.Leader;
-        if (grp.Candidate) {
-            for (uint32_t p = 0; p < b.slots && p < grp.Members.size(); p++) {
-                Node *m = grp.Members[p];
-                m->currentTerm = b.voterTermOut[(size_t)p * b.ld + g];
-                if ((b.stepdownMask[g] >> p) & 1u) m->nodeType = Follower;  // raft.go:221
+    ParallelOverGroups(b.groups, [&](uint32_t g0, uint32_t g1, uint32_t) {
+        for (uint32_t g = g0; g < g1; g++) {
+            Group &grp = groups[g];
+            Node *leader_before = grp.Leader;
+            if (grp.Candidate) {
+                for (uint32_t p = 0; p < b.slots && p < grp.Members.size(); p++) {
+                    Node *m = grp.Members[p];
+                    m->currentTerm = b.voterTermOut[(size_t)p * b.ld + g];
+                    if ((b.stepdownMask[g] >> p) & 1u) m->nodeType = Follower;  // raft.go:221
+                }
+                if (b.elected[g]) {
+                    grp.Candidate->BecomeLeader();
+                    grp.Leader = grp.Candidate;
+                    grp.Candidate = nullptr;
+                }
             }
-            if (b.elected[g]) {
-                grp.Candidate->BecomeLeader();
-                grp.Leader = grp.Candidate;
-                grp.Candidate = nullptr;
-            }
+            if (leader_before) leader_before->commitIndex = b.commitOut[g];
         }
-        if (leader_before) leader_before->commitIndex = b.commitOut[g];
-    }
+    });
 }
 
 template <typename T>
@@ -225,10 +274,10 @@ int BatchedDriver::EnsureEngine(int device, uint32_t groups, uint32_t slots, uin
 }
 
 int BatchedDriver::Step(int device) {
-    RoundBuffers b;
+    RoundBuffers &b = step_buffers_;
     int rc = Flatten(b);
     if (rc == kDriverRange) {               // some value needs more than 32 bits: wide layout
-        RoundBuffers64 w;
+        RoundBuffers64 &w = step_buffers64_;
         rc = Flatten(w);
         if (rc != kDriverOk) return rc == kDriverRange ? RQ_E_RANGE : RQ_E_ARG;
         rc = EnsureEngine(device, w.groups, w.slots, w.logTerm.size());

@@ -115,6 +115,13 @@ typedef RoundBuffersT<int64_t> RoundBuffers64;
 
 enum : int { kDriverOk = 0, kDriverRange = -2, kDriverShape = -1 };
 
+// Groups are independent, so the drivers walk them in parallel: fn(first, last,
+// worker) runs for disjoint group ranges on up to 16 host threads (one call on the
+// caller's thread below 32768 groups).  The reference is single-threaded
+// (raft.go has no goroutines); this only concerns the flattening of its objects.
+void ParallelOverGroups(uint32_t groups, const std::function<void(uint32_t, uint32_t, uint32_t)> &fn);
+uint32_t ParallelWorkers(uint32_t groups);
+
 // A group whose round hit a condition that is a Go panic in the reference:
 // status carries the RQ_ST_* bits (RQ_ST_EMPTY_LOG: a voter reached
 // lastEntry(log) with an empty log, raft.go:204/:235; RQ_ST_LOG_OOB: the leader's
@@ -168,6 +175,10 @@ private:
     uint32_t engine_groups_ = 0;
     bool last_step_wide_ = false;
     std::vector<GroupStatus> flagged_;
+    // Step's flat image, kept between calls (176 MB at 1M x 5: allocating and
+    // faulting it in afresh costs more than the round trip over PCIe)
+    RoundBuffers step_buffers_;
+    RoundBuffers64 step_buffers64_;
 };
 
 // ---- resident driver (no counterpart in the reference) ----------------------

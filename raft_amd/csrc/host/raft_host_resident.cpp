@@ -5,6 +5,8 @@
 #include "../../../include/rq.h"
 #include "raft_host.hpp"
 
+#include <atomic>
+
 namespace raft {
 
 namespace {
@@ -127,27 +129,39 @@ int ResidentDriver::Rebuild() {
     std::vector<uint16_t> om(G), nm(G);
     I.off.assign((size_t)G + 1, 0);
     I.cap.assign(G, 0);
-    std::vector<int32_t> row(words), terms;
     mixed_ = false;
+    // slice capacities from the leaders' log lengths, then the slices' places in the arena
     for (uint32_t g = 0; g < G; g++) {
-        int rc = FlattenRow(g, row.data(), terms);
-        if (rc != RQ_OK) return rc;
-        for (uint32_t p = 0; p < n; p++) {
-            match[p * ld + g] = row[p]; vt[p * ld + g] = row[n + p];
-            vf[p * ld + g] = row[2 * n + p]; ll[p * ld + g] = row[3 * n + p];
-        }
-        const int32_t *tail = row.data() + 4 * n;
-        commit[g] = tail[0]; lterm[g] = tail[1]; cterm[g] = tail[2]; cid[g] = tail[3];
-        om[g] = (uint16_t)((uint32_t)tail[5] & 0xFFFFu); nm[g] = (uint16_t)((uint32_t)tail[5] >> 16);
-        if (groups_[g].Members.size() != n) mixed_ = true;
-        len[g] = (uint32_t)terms.size();
-        I.cap[g] = slice_capacity(terms.size());
+        const Node *l = groups_[g].Leader;
+        I.cap[g] = slice_capacity(l ? l->log.size() : 0);
         const uint64_t next = (uint64_t)I.off[g] + I.cap[g];
         if (next > 0xFFFFFFFFull) return RQ_E_RANGE;
         I.off[g + 1] = (uint32_t)next;
-        arena.resize(next, 0);
-        std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * 4);
     }
+    arena.assign(I.off[G], 0);
+    // the groups themselves, in parallel (they are independent objects)
+    std::atomic<int> err{RQ_OK};
+    std::atomic<bool> mixed{false};
+    ParallelOverGroups(G, [&](uint32_t g0, uint32_t g1, uint32_t) {
+        std::vector<int32_t> row(words), terms;
+        for (uint32_t g = g0; g < g1; g++) {
+            int rc = FlattenRow(g, row.data(), terms);
+            if (rc == RQ_OK && terms.size() > I.cap[g]) rc = RQ_E_ARG;
+            if (rc != RQ_OK) { err.store(rc); return; }
+            for (uint32_t p = 0; p < n; p++) {
+                match[p * ld + g] = row[p]; vt[p * ld + g] = row[n + p];
+                vf[p * ld + g] = row[2 * n + p]; ll[p * ld + g] = row[3 * n + p];
+            }
+            const int32_t *tail = row.data() + 4 * n;
+            commit[g] = tail[0]; lterm[g] = tail[1]; cterm[g] = tail[2]; cid[g] = tail[3];
+            om[g] = (uint16_t)((uint32_t)tail[5] & 0xFFFFu); nm[g] = (uint16_t)((uint32_t)tail[5] >> 16);
+            if (groups_[g].Members.size() != n) mixed.store(true);
+            len[g] = (uint32_t)terms.size();
+            std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * 4);
+        }
+    });
+    if (err.load() != RQ_OK) return err.load();
+    mixed_ = mixed.load();
     // free space behind the slices: logs that outgrow their slice move there
     I.tail = arena.size();
     I.arena_entries = arena.size() + arena.size() / 2 + (1u << 16);
