@@ -147,6 +147,31 @@ def test_flatten_matches_the_objects_and_apply_matches_the_oracle():
         c.close()
 
 
+def test_flatten_and_apply_on_several_threads():
+    """At 32768 groups and more the driver walks the groups on several host threads
+    (two passes: log lengths, then everything); the flat image and the applied
+    objects must be what the single-threaded walk gives."""
+    G, n = 33000, 5
+    c, b = _build(G, n, seed=23)
+    try:
+        rc, f = c.flatten()
+        assert rc == 0
+        for k in ("match", "commit", "leader_term", "log_off", "log_term", "voter_term", "voted_for",
+                  "last_log_term", "cand_term", "cand_id"):
+            assert np.array_equal(f[k], b[k]), k
+        r = o.fused_round(*b.fused_args())
+        c.apply(r)
+        for g in list(range(0, G, 97)) + [G - 1]:
+            lead, cand = int(b.cand_id[g] + 1) % n, int(b.cand_id[g])
+            for p in range(n):
+                assert c.get(g, p)["currentTerm"] == r.voter_term[p, g]
+            assert c.get(g, lead)["commitIndex"] == r.commit[g]
+            new_lead, new_cand = c.get_roles(g)
+            assert (new_lead, new_cand) == ((cand, -1) if r.elected[g] else (lead, cand))
+    finally:
+        c.close()
+
+
 def test_flatten_rejects_values_outside_int32():
     c = h.Cluster(1, 3)
     try:
