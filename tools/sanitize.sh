@@ -12,7 +12,7 @@ cp raft_amd/libraft_host.so build/asan/host_orig.so
 restore() { cp build/asan/oracle_orig.so oracle/librq_oracle.so; cp build/asan/host_orig.so raft_amd/libraft_host.so; }
 trap restore EXIT
 gcc $SAN -std=c11 -fPIC -shared -pthread oracle/raft_oracle.c -o oracle/librq_oracle.so
-g++ $SAN -std=c++17 -fPIC -shared raft_amd/csrc/host/raft_host.cpp raft_amd/csrc/host/raft_host_capi.cpp \
+g++ $SAN -std=c++17 -fPIC -shared -pthread raft_amd/csrc/host/raft_host.cpp raft_amd/csrc/host/raft_host_resident.cpp raft_amd/csrc/host/raft_host_capi.cpp \
     -Lraft_amd -lrq -Wl,-rpath,'$ORIGIN' -o raft_amd/libraft_host.so
 LD_PRELOAD="$PRE${LD_PRELOAD:+ $LD_PRELOAD}" ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1 \
     python -m pytest tests/test_oracle_kats.py tests/test_host_cpp.py tests/test_wide_layout.py -x -q -m "not gpu"
