@@ -221,6 +221,17 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
                             note="log-term arena kept as int32 entries")
     del sets
     torch.cuda.empty_cache()
+    # no arena on the device: the host keeps, per group, the index of the first entry of the
+    # leader's term (rq_round_desc.log_term_start); logs of Raft's own shape (terms above the
+    # leader's lowered to it)
+    sets = [DeviceBatch(b, device, tiled=tiled, term_start=synth.term_start_monotone(b)) for b in host_batches]
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(sets[i % S]), steps, warmup, S)
+    tsb = alg_bytes_per_group(n) - 4                  # term start + length instead of term, offset and looked-up term
+    out["term_start"] = dict(kernel_ms=ms, frac=frac(tsb, ms), input_sets=S, alg_bytes_per_group=tsb,
+                             note="log_term_start instead of the log-term lookup (logs non-decreasing, none above "
+                                  "the leader's term); nothing of the logs resident")
+    del sets
+    torch.cuda.empty_cache()
     # the headline workload in slot-major planes (the layout of the host-buffer entry points)
     sets = [DeviceBatch(b, device, log_term_bits=args.log_term_bits, tiled=False) for b in host_batches]
     ms = timed_launches(torch, device, lambda i: eng.fused_round(sets[i % S]), steps, warmup, S)
@@ -281,9 +292,15 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     # mixed 3-9 peers + 10 % joint consensus, Zipf log lengths; one log arena shared by the sets
     first = synth.gen_mixed(G, seed=500)
     msets = [DeviceBatch(first, device, tiled=tiled)]
+    mstart = [synth.term_start_monotone(first)]
+    mhost = [first]
     for s in range(1, 8):
-        msets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), device, share_log_with=msets[0],
-                                 tiled=tiled))
+        mb = synth.gen_mixed(G, seed=500 + s, logs_from=first)
+        msets.append(DeviceBatch(mb, device, share_log_with=msets[0], tiled=tiled))
+        mstart.append(synth.term_start_monotone(mb))
+        mb = synth.Batch(mb)
+        mb["log_term"] = first["log_term"][:1]          # the arena is not needed again: let it go
+        mhost.append(mb)
     mem = (first.old_mask | first.new_mask).astype(np.int64)
     members = float(sum((mem >> p) & 1 for p in range(16)).mean())
     bpg = 20 * members + 41
@@ -292,6 +309,14 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     out["mixed"] = dict(kernel_ms=ms, frac=frac(bpg, ms), input_sets=S, alg_bytes_per_group=bpg,
                         mean_member_slots=members,
                         note="mixed 3-9 peers + 10% joint consensus, Zipf(1.2) logs up to 4096 entries")
+    del msets
+    torch.cuda.empty_cache()
+    # the same workload without the log arena (log_term_start): a looked-up term costs a
+    # 128-byte line of its own once logs are hundreds of entries long
+    msets = [DeviceBatch(mb, device, tiled=tiled, term_start=ts) for mb, ts in zip(mhost, mstart)]
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(msets[i % S]), steps, warmup, S)
+    out["mixed_term_start"] = dict(kernel_ms=ms, frac=frac(bpg - 4, ms), input_sets=S, alg_bytes_per_group=bpg - 4,
+                                   note="mixed / joint workload with log_term_start instead of the lookup")
     del msets
     torch.cuda.empty_cache()
     return out

@@ -285,6 +285,19 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  *               advance, which a receiver adds to the commitIndex it already
  *               holds (xGMI links are point-to-point, so the bytes per group on
  *               the wire decide how far the exchange of a 30 us round scales).
+ *   log_term_start   may be NULL.  Else the round makes NO arena lookup: the test
+ *               log[N].TermNum == currentTerm is evaluated as N >= log_term_start[g],
+ *               the index (in matchIndex's index space) of the first entry of the
+ *               leader's current term, or the index one past its last entry when
+ *               it has none yet.  The two are the same whenever the terms of a log
+ *               never decrease and never exceed the leader's term -- every log Raft
+ *               itself produces; the reference does not enforce it (raft.go:158-170
+ *               appends whatever it is sent), so the lookup stays the default.  A
+ *               host knows the value when it appends.  log_len is then required
+ *               (N outside [log_base, log_base + log_len) is RQ_ST_LOG_OOB as before);
+ *               log_off, log_term and leader_term are not read.  One gathered term
+ *               costs a 128-byte HBM line of its own once logs are long: at 1M
+ *               groups with Zipf log lengths this path moves 40 MB less per round.
  *   tile_bytes / out_tile_bytes   0: every array is a slot-major plane,
  *               field[p * ld + g].  Else the tiled layout: groups are cut into
  *               tiles of 64; tile t of the INPUT block holds the elements of its
@@ -348,6 +361,7 @@ typedef struct rq_round_desc {
     const void *summary_base;
     uint32_t *summary_escapes;
     uint64_t *start_signal;     /* may be NULL (see rq_stream_wait_signal) */
+    const void *log_term_start; /* may be NULL (see above) */
 } rq_round_desc;
 
 int rq_round_dev(rq_engine *e, void *stream, const rq_round_desc *d);

@@ -36,7 +36,7 @@ class RoundDesc(C.Structure):
                 ("elected", vp), ("max_term", vp), ("status_out", vp), ("elected_bits", vp),
                 ("changed_bits", vp),
                 ("commit_summary", vp), ("summary_base", vp), ("summary_escapes", vp),
-                ("start_signal", vp)]
+                ("start_signal", vp), ("log_term_start", vp)]
 
 
 class AppendDesc(C.Structure):

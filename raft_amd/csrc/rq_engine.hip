@@ -295,8 +295,13 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     if (d.n < 1 || d.n > RQ_MAX_SLOTS || (d.ld < d.G && !d.tile_bytes) || d.G > 0x7FFFFFFFu || d.reserved != 0) return RQ_E_ARG;
     if ((d.old_mask == nullptr) != (d.new_mask == nullptr)) return RQ_E_ARG;
     if (what & RQ_WHAT_COMMIT) {
-        if (!d.match || !d.commit || !d.leader_term || !d.log_off || !d.commit_out) return RQ_E_ARG;
-        if (!d.log_term && d.log_terms != 0) return RQ_E_ARG;
+        if (!d.match || !d.commit || !d.commit_out) return RQ_E_ARG;
+        if (d.log_term_start) {                       // no arena lookup: index of the term's first entry + log length
+            if (!d.log_len) return RQ_E_ARG;
+        } else {
+            if (!d.leader_term || !d.log_off) return RQ_E_ARG;
+            if (!d.log_term && d.log_terms != 0) return RQ_E_ARG;
+        }
         if (d.log_terms > 0xFFFFFFFFull) return RQ_E_ARG;
         const uint32_t tb = d.log_term_bits;
         if (tb != 0 && tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return RQ_E_ARG;
@@ -321,6 +326,7 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     a.log_off = d.log_off; a.log_term = d.log_term;
     a.log_base = (const T *)d.log_base; a.log_term_base = (const T *)d.log_term_base;
     a.log_len = d.log_len;
+    a.log_term_start = (const T *)d.log_term_start;
     a.log_terms = d.log_terms;
     a.log_term_bits = d.log_term_bits ? d.log_term_bits : (uint32_t)(8 * sizeof(T));
     a.voter_term = (const T *)d.voter_term; a.voted_for = (const T *)d.voted_for;

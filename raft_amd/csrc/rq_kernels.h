@@ -24,6 +24,11 @@ struct rq_round_args_t {
     const T *log_base;        // may be null (0): arena slot 0 of group g holds log[log_base[g]]
     const T *log_term_base;   // may be null (0): added to every arena entry of group g
     const uint32_t *log_len;  // may be null: group g's log is the first log_len[g] entries of its slice
+    // may be null.  Else no arena lookup: log[N].TermNum == leader_term is taken to be
+    // N >= log_term_start[g], the index of the first entry of the leader's current term
+    // (valid for logs whose terms never decrease and never exceed the leader's term, as
+    // Raft's own logs); log_len is then required, log_off / log_term / leader_term unused.
+    const T *log_term_start;
     uint64_t log_terms;       // entries in the arena: no lookup goes at or beyond it
     uint32_t log_term_bits;   // 8, 16 (unsigned entries), 32 (signed) or 8 * sizeof(T)
     // vote side (RequestVoteRPC inputs, raft.go:181-210)

@@ -410,10 +410,10 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     const group_addr gco = (const void *)a.commit_out == (const void *)a.commit ? ga : go;
     const group_addr gvo = (const void *)a.voter_term_out == (const void *)a.voter_term ? ga : go;
 
-    T mt[N][V], cm[V], lt[V], lb[V], tb[V];
+    T mt[N][V], cm[V], lt[V], lb[V], tb[V], ts[V];
     int32_t off[V + 1], ln[V];
 #pragma unroll
-    for (int k = 0; k < V; k++) { lb[k] = 0; tb[k] = 0; ln[k] = 0; }
+    for (int k = 0; k < V; k++) { lb[k] = 0; tb[k] = 0; ln[k] = 0; lt[k] = 0; ts[k] = 0; }
     T vt[N][V], vf[N][V], ll[N][V], ct[V], ci[V];
     uint32_t st[V];
 #pragma unroll
@@ -424,19 +424,25 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 #pragma unroll
         for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
         ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
-        ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
         if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
-        if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
         if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
-        const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
-        int32_t o[V];
-        ld_i32<V, NTL, FULL>(offp, valid, o);
-        // plain on purpose: it re-reads the line the vector load above brought in
-        // (non-temporal here bypasses L1 and was measured 1 us slower per round)
-        const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));  // log_off has G+1 entries
+        if (a.log_term_start) {
+            ld_i32<V, NTL, FULL>(at(a.log_term_start, ga), valid, ts);
 #pragma unroll
-        for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
-        off[V] = oend;
+            for (int k = 0; k <= V; k++) off[k] = 0;
+        } else {
+            ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
+            if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
+            const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
+            int32_t o[V];
+            ld_i32<V, NTL, FULL>(offp, valid, o);
+            // plain on purpose: it re-reads the line the vector load above brought in
+            // (non-temporal here bypasses L1 and was measured 1 us slower per round)
+            const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));  // log_off has G+1 entries
+#pragma unroll
+            for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
+            off[V] = oend;
+        }
     }
     if constexpr (DO_VOTE) {
 #pragma unroll
@@ -450,9 +456,10 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     }
 
     // ---- commit: quorum index, then the dependent log-term gather ----
-    T nq[V], gt[V];
-    bool adv[V], inb[V];
+    T nq[V];
+    bool adv[V], inb[V], hit[V];
     if constexpr (DO_COMMIT) {
+        const bool by_start = a.log_term_start != nullptr;     // uniform: no arena lookup
 #pragma unroll
         for (int k = 0; k < V; k++) {
             T s[N];
@@ -460,15 +467,15 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             for (int p = 0; p < N; p++) s[p] = mt[p][k];
             nq[k] = quorum_index<N>(s);
             const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
-            const bool csr = a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms);
+            const bool csr = by_start || (a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms));
             const uint32_t len = a.log_len ? (uint32_t)ln[k] : end - beg;
             const U wi = window_slot(nq[k], lb[k]);
             adv[k] = (k < valid) && nq[k] > cm[k];
             inb[k] = csr && wi < (U)len;
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
-            gt[k] = 0;
-            if (adv[k] && inb[k])
-                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
+            hit[k] = by_start && nq[k] >= ts[k];
+            if (!by_start && adv[k] && inb[k])
+                hit[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]) == lt[k];
         }
     }
 
@@ -510,7 +517,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
         T co[V];
 #pragma unroll
         for (int k = 0; k < V; k++) {
-            co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
+            co[k] = (adv[k] && inb[k] && hit[k]) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
             if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
@@ -703,8 +710,8 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         issue_chunk(0);
     }
 
-    T nq[V], gt[V], cm[V], lt[V];
-    bool adv[V], inb[V];
+    T nq[V], cm[V], lt[V];
+    bool adv[V], inb[V], hit[V];
     if constexpr (DO_COMMIT) {
         T mt[MMAX][V];
         int32_t off[V + 1];
@@ -716,24 +723,29 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
                 if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
             }
         }
-        T lb[V], tb[V];
+        T lb[V], tb[V], ts[V];
         int32_t ln[V];
+        const bool by_start = a.log_term_start != nullptr;     // uniform: no arena lookup
 #pragma unroll
-        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; tb[k] = 0; ln[k] = 0; }
+        for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; tb[k] = 0; ln[k] = 0; ts[k] = 0; }
         off[V] = 0;
         if (in_range) {
             ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
-            ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
             if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
-            if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
             if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
-            const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
-            int32_t o[V];
-            ld_i32<V, NTL, FULL>(offp, valid, o);
-            const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));
+            if (a.log_term_start) {
+                ld_i32<V, NTL, FULL>(at(a.log_term_start, ga), valid, ts);
+            } else {
+                ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
+                if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
+                const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
+                int32_t o[V];
+                ld_i32<V, NTL, FULL>(offp, valid, o);
+                const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));
 #pragma unroll
-            for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
-            off[V] = oend;
+                for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
+                off[V] = oend;
+            }
         }
         // one configuration for the whole wave (the common case) needs one sort
         bool two_cfgs = false;
@@ -753,15 +765,15 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             }
             nq[k] = tmin(no, nn);
             const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
-            const bool csr = a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms);
+            const bool csr = by_start || (a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms));
             const uint32_t len = a.log_len ? (uint32_t)ln[k] : end - beg;
             const U wi = window_slot(nq[k], lb[k]);
             adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
             inb[k] = csr && wi < (U)len;
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
-            gt[k] = 0;
-            if (adv[k] && inb[k])
-                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
+            hit[k] = by_start && nq[k] >= ts[k];
+            if (!by_start && adv[k] && inb[k])
+                hit[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]) == lt[k];
         }
     }
 
@@ -794,7 +806,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         T co[V];
 #pragma unroll
         for (int k = 0; k < V; k++) {
-            co[k] = (adv[k] && inb[k] && gt[k] == lt[k]) ? nq[k] : cm[k];
+            co[k] = (adv[k] && inb[k] && hit[k]) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
             if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
@@ -906,6 +918,7 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     const uint32_t tb = args.log_term_bits;
     if ((what & RQ_WHAT_COMMIT) && tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
     if (!aligned_to(args.start_signal, 8)) return hipErrorInvalidValue;
+    if ((what & RQ_WHAT_COMMIT) && args.log_term_start && !args.log_len) return hipErrorInvalidValue;
     if (variant & ~(RQ_VAR_PLAIN | 0xF00)) return hipErrorInvalidValue;
     const int bsel = (variant >> 8) & 0xF;
     if (bsel > 4) return hipErrorInvalidValue;

@@ -84,7 +84,8 @@ class DeviceBatch:
 
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
                  share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None,
-                 summary_bits=16, log_term_bits=None, log_term_base=False, tiled=False, start_signal=None):
+                 summary_bits=16, log_term_bits=None, log_term_base=False, tiled=False, start_signal=None,
+                 term_start=False):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         share_log_with: another DeviceBatch whose log_off/log_term device arrays
@@ -102,7 +103,11 @@ class DeviceBatch:
         ONE block of 64-group tiles (rq_round_desc.tile_bytes) instead of separate
         slot-major planes; the log arena and the bit summaries stay plain arrays.
         start_signal: device address of a signal word the launch bumps when it starts
-        (everything enqueued before it on its stream has completed by then)."""
+        (everything enqueued before it on its stream has completed by then).
+        term_start=True: no log arena on the device at all -- per group the index of the
+        first entry of the leader's term and the log length (synth.term_start_form, or
+        the two arrays themselves; the batch's logs must be non-decreasing and not
+        above the leader's term)."""
         self.start_signal = start_signal
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
@@ -122,7 +127,16 @@ class DeviceBatch:
                 batch["log_term"], batch["log_off"], 0 if log_term_bits is None else log_term_bits, log_term_base)
             if tbase is not None:
                 host["log_term_base"] = np.ascontiguousarray(tbase, dtype=vdt)
+        self.term_start = bool(term_start)
+        if term_start:
+            from . import synth
+            ts, ln = term_start if isinstance(term_start, tuple) else synth.term_start_form(batch)
+            host["log_term_start"] = np.ascontiguousarray(ts, dtype=vdt)
+            host["log_len"] = np.ascontiguousarray(ln.view(np.int32))
+            self.log_terms = 0
         for k in self.IN_KEYS:
+            if term_start and k in ("log_off", "log_term", "leader_term"):
+                continue                        # not read by a round that knows where the term starts
             if share_log_with is not None and (k == "log_term" or (k == "log_off" and not tiled)):
                 continue                        # (a tiled batch keeps its offsets inside its own tiles)
             a = batch[k]
@@ -355,8 +369,9 @@ class DeviceEngine:
         d.summary_bits = b.summary_bits
         d.old_mask, d.new_mask = p(t.get("old_mask")), p(t.get("new_mask"))
         if commit:
-            d.match, d.commit, d.leader_term = p(t["match"]), p(t["commit"]), p(t["leader_term"])
-            d.log_off, d.log_term = p(t["log_off"]), p(t["log_term"])
+            d.match, d.commit, d.leader_term = p(t["match"]), p(t["commit"]), p(t.get("leader_term"))
+            d.log_off, d.log_term = p(t.get("log_off")), p(t.get("log_term"))
+            d.log_term_start = p(t.get("log_term_start"))
             d.log_base, d.log_term_base = p(t.get("log_base")), p(t.get("log_term_base"))
             d.log_len = p(t.get("log_len"))
             d.commit_out = p(o["commit_out"])

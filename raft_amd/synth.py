@@ -139,7 +139,7 @@ def gen_fused(G, n=5, seed=DEFAULT_SEED, ld=None, max_len=16, tmax=8):
     vt, vf, ll, ct, ci = _vote_side(seed, G, n, ld, 2 + T)
     return Batch(G=G, n=n, ld=ld, match=match, commit=commit, leader_term=leader_term,
                  log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
-                 last_log_term=ll, cand_term=ct, cand_id=ci)
+                 last_log_term=ll, cand_term=ct, cand_id=ci, log_T=T)
 
 
 def gen_commit_small(G=10000, n=3, seed=DEFAULT_SEED, log_len=32):
@@ -212,6 +212,56 @@ def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi
                  log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
                  last_log_term=ll, cand_term=ct, cand_id=ci, old_mask=old_mask, new_mask=new_mask,
                  log_T=T)
+
+
+def raft_valid(b):
+    """The batch with every log term above its leader's term lowered to that term: with
+    the generators' non-decreasing logs that is the shape of every log Raft itself
+    produces (terms never decrease, none above the leader's term)."""
+    out = Batch(b)
+    off = b["log_off"].astype(np.int64)
+    G = off.size - 1
+    lens = np.diff(off)
+    total = int(off[-1])
+    lt = np.repeat(b["leader_term"][:G], lens)
+    terms = b["log_term"].copy()
+    terms[:total] = np.minimum(terms[:total], lt.astype(terms.dtype))
+    out["log_term"] = terms
+    return out
+
+
+def term_start_form(b):
+    """(log_term_start[G], log_len[G]) of a batch: per group the index -- in matchIndex's
+    index space, so the log window base is added -- of the first log entry whose term equals
+    the leader's term, or one past the last entry if there is none; and the log's length."""
+    off = b["log_off"].astype(np.int64)
+    G = off.size - 1
+    lens = np.diff(off)
+    total = int(off[-1])
+    lt = np.repeat(b["leader_term"][:G].astype(np.int64), lens)
+    pos = np.arange(total, dtype=np.int64) - np.repeat(off[:-1], lens)
+    cand = np.where(b["log_term"][:total].astype(np.int64) == lt, pos, np.repeat(lens, lens))
+    start = lens.copy()
+    nz = lens > 0
+    if nz.any():
+        start[nz] = np.minimum.reduceat(cand, off[:-1][nz])
+    if "log_base" in b:
+        start = start + b["log_base"][:G].astype(np.int64)
+    return start.astype(b["match"].dtype), lens.astype(np.uint32)
+
+
+def term_start_monotone(b):
+    """term_start_form(raft_valid(b)) for a gen_fused / gen_mixed batch without touching the
+    arena (hundreds of MB for the mixed workload): the generators' logs are
+    term_at(i) = 1 + floor(i * T / len), so the first entry at or above the leader's
+    term t is i = ceil((t - 1) * len / T), or there is none."""
+    lens = np.diff(b["log_off"].astype(np.int64))
+    G = lens.size
+    T = b["log_T"].astype(np.int64)
+    t = b["leader_term"][:G].astype(np.int64)
+    first = np.where(t <= 1, 0, -((-(t - 1) * lens) // T))
+    start = np.minimum(first, lens)
+    return start.astype(b["match"].dtype), lens.astype(np.uint32)
 
 
 def gen_adversarial(G, n, seed=DEFAULT_SEED, ld=None):

@@ -1410,3 +1410,51 @@ def test_round_start_signal(dev, kind):
     bad = DeviceBatch(synth.gen_fused(100, 3, seed=1), start_signal=first.o["elected"].data_ptr() + 4)
     with pytest.raises(Exception):
         dev.fused_round(bad)
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+@pytest.mark.parametrize("kind", ["fixed", "joint", "wide", "window"])
+def test_term_start_instead_of_the_arena_lookup(dev, kind, tiled):
+    """rq_round_desc.log_term_start: on logs of Raft's own shape (terms never decrease,
+    none above the leader's term) `N >= index of the term's first entry` is the same
+    decision as log[N].TermNum == currentTerm, so the round needs no arena on the
+    device.  Checked against the oracle, which looks the term up."""
+    from raft_amd.device import DeviceBatch
+    if kind == "joint":
+        b = synth.raft_valid(synth.gen_mixed(30011, seed=81))
+        kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
+    elif kind == "window":
+        b = synth.raft_valid(synth.window_logs(synth.gen_fused(40001, 5, seed=82), keep_committed=1))
+        kw = dict(log_base=b.log_base)
+    else:
+        b = synth.raft_valid(synth.gen_fused(40001, 5, seed=83))
+        kw = {}
+    G = int(b["G"])
+    b["match"] = b["match"].copy()
+    b["match"][:, ::97] += 100                                  # quorum index beyond the log: status bit, no advance
+    b["leader_term"] = b["leader_term"].copy()
+    b["leader_term"][5::11] += 3                                # a term the log has no entry of yet: no advance
+    if kind == "wide":
+        b, _ = synth.widen(b, index_shift=0, term_shift=1 << 40, id_shift=1 << 41, seed=5)
+        exp = o.round64(3, *b.fused_args())
+    else:
+        exp = o.fused_round(*b.fused_args(), **kw)
+    ts, ln = synth.term_start_form(b)
+    assert (ts.astype(np.int64) < (ln.astype(np.int64) + (b["log_base"] if "log_base" in b else 0))).mean() > 0.3
+    db = DeviceBatch(b, term_start=True, tiled=tiled)
+    assert "log_term" not in db.t and "log_off" not in db.t and "leader_term" not in db.t
+    dev.fused_round(db)
+    got = db.results()
+    assert np.array_equal(got["commit"], exp["commit"])
+    assert np.array_equal(got["status"], exp["status"])
+    assert np.array_equal(got["elected"], exp["elected"]) and np.array_equal(got["max_term"], exp["max_term"])
+    assert np.array_equal(got["grant_mask"], exp["grant_mask"])
+    advanced = got["commit"] != b["commit"][:G]
+    assert 0.1 < advanced.mean() < 0.9 and (got["status"] & 1).any()
+    # commit decision alone, and the same answers as the arena lookup on the device
+    arena = DeviceBatch(b, tiled=tiled)
+    dev.fused_round(arena)
+    assert np.array_equal(arena.results()["commit"], got["commit"])
+    only = DeviceBatch(b, term_start=True, tiled=tiled)
+    dev.commit_advance(only)
+    assert np.array_equal(only.results()["commit"], exp["commit"])

@@ -382,3 +382,35 @@ def test_joint_oracle_equals_numpy_closed_form():
         assert np.array_equal(r.elected.astype(bool), el)
         assert np.array_equal(r.voter_term[member], np.maximum(vt, t)[member].astype(np.int32))
         assert np.array_equal(r.voter_term[~member], b.voter_term[~member])
+
+
+def test_term_start_rule_equals_the_lookup_on_raft_shaped_logs():
+    """On logs whose terms never decrease and never exceed the leader's term,
+    log[N].TermNum == currentTerm is the same as N >= (index of the term's first
+    entry): the oracle, which looks the term up, against the rule in numpy; and the
+    closed form the bench uses for its generated logs against a scan of the arena."""
+    from raft_amd import synth
+    for b0 in (synth.gen_fused(20011, 5, seed=31), synth.gen_mixed(9001, seed=32),
+               synth.window_logs(synth.gen_fused(7000, 3, seed=33), keep_committed=2)):
+        b = synth.raft_valid(b0)
+        G = int(b["G"])
+        kw = {}
+        if "old_mask" in b:
+            kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
+            N = np.minimum(synth.masked_quorum_index(b.match[:, :G], b.old_mask),
+                           synth.masked_quorum_index(b.match[:, :G], b.new_mask)).astype(np.int64)
+        else:
+            N = synth.quorum_index(b.match[:, :G]).astype(np.int64)
+        if "log_base" in b:
+            kw["log_base"] = b.log_base
+        exp, st = o.commit_advance(*b.commit_args(), **kw)
+        start, ln = synth.term_start_form(b)
+        base = b["log_base"].astype(np.int64) if "log_base" in b else 0
+        commit = b.commit[:G].astype(np.int64)
+        in_log = (N >= base) & (N < base + ln)
+        rule = np.where((N > commit) & in_log & (N >= start), N, commit)
+        assert np.array_equal(rule, exp.astype(np.int64))
+        assert np.array_equal((st & 1).astype(bool), (N > commit) & ~in_log)
+        if "log_base" not in b0:
+            s2, l2 = synth.term_start_monotone(b0)
+            assert np.array_equal(s2, start) and np.array_equal(l2, ln)
