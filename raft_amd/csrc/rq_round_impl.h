@@ -424,15 +424,17 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 #pragma unroll
         for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
         ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
-        if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
-        if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
         if (a.log_term_start) {
+            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
+            ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
             ld_i32<V, NTL, FULL>(at(a.log_term_start, ga), valid, ts);
 #pragma unroll
             for (int k = 0; k <= V; k++) off[k] = 0;
         } else {
             ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
+            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
             if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
+            if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
             const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
             int32_t o[V];
             ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -456,10 +458,10 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     }
 
     // ---- commit: quorum index, then the dependent log-term gather ----
-    T nq[V];
-    bool adv[V], inb[V], hit[V];
+    T nq[V], gt[V];
+    bool adv[V], inb[V];
+    const bool by_start = a.log_term_start != nullptr;         // uniform: no arena lookup
     if constexpr (DO_COMMIT) {
-        const bool by_start = a.log_term_start != nullptr;     // uniform: no arena lookup
 #pragma unroll
         for (int k = 0; k < V; k++) {
             T s[N];
@@ -473,9 +475,9 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             adv[k] = (k < valid) && nq[k] > cm[k];
             inb[k] = csr && wi < (U)len;
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
-            hit[k] = by_start && nq[k] >= ts[k];
+            gt[k] = 0;
             if (!by_start && adv[k] && inb[k])
-                hit[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]) == lt[k];
+                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
         }
     }
 
@@ -517,7 +519,8 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
         T co[V];
 #pragma unroll
         for (int k = 0; k < V; k++) {
-            co[k] = (adv[k] && inb[k] && hit[k]) ? nq[k] : cm[k];
+            const bool hit = by_start ? nq[k] >= ts[k] : gt[k] == lt[k];     // the looked-up term is consumed here, late
+            co[k] = (adv[k] && inb[k] && hit) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
             if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
@@ -710,8 +713,9 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         issue_chunk(0);
     }
 
-    T nq[V], cm[V], lt[V];
-    bool adv[V], inb[V], hit[V];
+    T nq[V], gt[V], cm[V], lt[V], ts[V];
+    bool adv[V], inb[V];
+    const bool by_start = a.log_term_start != nullptr;         // uniform: no arena lookup
     if constexpr (DO_COMMIT) {
         T mt[MMAX][V];
         int32_t off[V + 1];
@@ -723,21 +727,22 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
                 if ((anymem >> p) & 1u) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
             }
         }
-        T lb[V], tb[V], ts[V];
+        T lb[V], tb[V];
         int32_t ln[V];
-        const bool by_start = a.log_term_start != nullptr;     // uniform: no arena lookup
 #pragma unroll
         for (int k = 0; k < V; k++) { cm[k] = 0; lt[k] = 0; off[k] = 0; lb[k] = 0; tb[k] = 0; ln[k] = 0; ts[k] = 0; }
         off[V] = 0;
         if (in_range) {
             ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
-            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
-            if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
             if (a.log_term_start) {
+                if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
+                ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
                 ld_i32<V, NTL, FULL>(at(a.log_term_start, ga), valid, ts);
             } else {
                 ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
+                if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
                 if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
+                if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
                 const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
                 int32_t o[V];
                 ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -771,9 +776,9 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             adv[k] = (k < valid) && mem[k] != 0 && nq[k] > cm[k];
             inb[k] = csr && wi < (U)len;
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
-            hit[k] = by_start && nq[k] >= ts[k];
+            gt[k] = 0;
             if (!by_start && adv[k] && inb[k])
-                hit[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]) == lt[k];
+                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
         }
     }
 
@@ -806,7 +811,8 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
         T co[V];
 #pragma unroll
         for (int k = 0; k < V; k++) {
-            co[k] = (adv[k] && inb[k] && hit[k]) ? nq[k] : cm[k];
+            const bool hit = by_start ? nq[k] >= ts[k] : gt[k] == lt[k];     // the looked-up term is consumed here, late
+            co[k] = (adv[k] && inb[k] && hit) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
             if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
         }
