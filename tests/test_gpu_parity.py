@@ -1225,7 +1225,7 @@ def test_groups_scatter_gather_and_changed_bits(dev, wide):
         rows = np.zeros((K, words), dt)
         roff = np.zeros(K + 1, np.uint32)
         rterms, tail = [], tail0
-        cur = synth.Batch(b)                                      # what the device holds after round 1
+        cur = synth.Batch(b)                                      # what the device holds after the first round
         cur["commit"], cur["voter_term"] = exp["commit"].copy(), exp["voter_term"].copy()
         edited = synth.Batch({k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in cur.items()})
         new_logs = {}
