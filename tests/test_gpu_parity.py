@@ -788,7 +788,7 @@ def test_fuzz_layouts_windows_and_summaries(dev):
     from raft_amd.device import DeviceBatch, summary_buffer_bytes
     rng = np.random.default_rng(77)
     variants = [0, 1, 0x100, 0x101, 0x200, 0x301, 0x400]
-    for it in range(48):
+    for it in range(96):
         G = int(rng.integers(1, 2500))
         wide, joint, window = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
         bits = int(rng.choice([0, 4, 8, 16]))
@@ -802,6 +802,10 @@ def test_fuzz_layouts_windows_and_summaries(dev):
         if window:
             b = synth.window_logs(b, keep_committed=int(rng.integers(0, 3)))
             kw["log_base"] = b.log_base
+        tiled = bool(rng.integers(2))
+        by_start = bool(rng.integers(3) == 0)                   # no arena: index where the leader's term starts
+        if by_start:
+            b = synth.raft_valid(b)
         exp = o.fused_round(*b.fused_args(), G=G, **kw)
         batch = synth.widen(b)[0] if wide else b
         skw = {}
@@ -811,10 +815,13 @@ def test_fuzz_layouts_windows_and_summaries(dev):
                        summary_escapes=torch.zeros(2, dtype=torch.int32, device="cuda:0"),
                        summary_bits=bits, summary_base="commit" if base_kind == "commit" else None)
         tbits = [None, 0, 8, 16, 32][int(rng.integers(5))]      # log-term arena entry width (None = full)
-        db = DeviceBatch(batch, log_term_bits=tbits, log_term_base=bool(rng.integers(2)), **skw)
+        if by_start:
+            db = DeviceBatch(batch, term_start=True, tiled=tiled, **skw)
+        else:
+            db = DeviceBatch(batch, log_term_bits=tbits, log_term_base=bool(rng.integers(2)), tiled=tiled, **skw)
         dev.fused_round(db, variant=variant)
         res = db.results()
-        case = (it, G, wide, joint, window, bits, hex(variant), tbits, db.log_term_bits)
+        case = (it, G, wide, joint, window, bits, hex(variant), tbits, db.log_term_bits, tiled, by_start)
         mem = member_matrix(b)[:, :G] if joint else np.ones((b.n, G), bool)
         for f in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
             assert np.array_equal(res[f][:G].astype(np.int64), exp[f][:G].astype(np.int64)), (f, case)
