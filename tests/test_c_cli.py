@@ -76,10 +76,13 @@ def test_cli_known_answers_and_seeded_batch(mode):
 def test_plain_c_benchmark_runs():
     """examples/rq_bench: device memory, a plan and the timed loop through the C-ABI alone."""
     exe = os.path.join(ROOT, "examples", "rq_bench")
-    p = subprocess.run([exe, "65536", "5", "4", "60", "12"], capture_output=True, text=True, timeout=120)
-    assert p.returncode == 0, p.stderr
-    f = p.stdout.split()
-    assert [int(x) for x in f[:4]] == [65536, 5, 4, 60]
-    assert float(f[4]) > 0 and float(f[7]) > 0
-    share = float(p.stderr.split("elected")[1].split("%")[0])
-    assert 10 < share < 90                      # the drawn batch elects a plausible share of its groups
+    shares = []
+    for layout in ("tiles", "planes"):                         # the same drawn batch in both layouts
+        p = subprocess.run([exe, "65537", "5", "4", "60", "12", "8", layout], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0, p.stderr
+        f = p.stdout.split()
+        assert [int(x) for x in f[:4]] == [65537, 5, 4, 60]
+        assert float(f[4]) > 0 and float(f[7]) > 0
+        shares.append(p.stderr.split("elected")[1].split("%")[0])
+    assert shares[0] == shares[1]                              # identical decisions
+    assert 10 < float(shares[0]) < 90                          # a plausible share of the groups elects
