@@ -277,16 +277,26 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     torch.cuda.empty_cache()
 
     # wide layout on the first sets (8 output sets x 66 MB exceed the Infinity Cache)
-    wide = []
-    for s, b in enumerate(host_batches[:8]):
-        w, _ = synth.widen(b, index_shift=0, term_shift=1 << 41, id_shift=1 << 42, seed=1000 + s)
-        wide.append(DeviceBatch(w, device, tiled=tiled))
+    whost = [synth.widen(b, index_shift=0, term_shift=1 << 41, id_shift=1 << 42, seed=1000 + s)[0]
+             for s, b in enumerate(host_batches[:8])]
+    wide = [DeviceBatch(w, device, tiled=tiled) for w in whost]
     S = len(wide)
     ms = timed_launches(torch, device, lambda i: eng.fused_round(wide[i % S]), steps, warmup, S)
     out["i64"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n, "fused", "i64"), ms), input_sets=S,
                       alg_bytes_per_group=alg_bytes_per_group(n, "fused", "i64"),
-                      note="rq_round64_dev, terms and ids shifted beyond 2^41")
+                      note="rq_round64_dev, terms and ids shifted beyond 2^41, int64 arena entries")
     del wide
+    torch.cuda.empty_cache()
+    # the same with the arena as a host would keep it: entries as narrow as the differences from each
+    # group's smallest resident term allow (8 bits here), the base term in a plane of its own
+    wide = [DeviceBatch(w, device, tiled=tiled, log_term_bits=0, log_term_base=True) for w in whost]
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(wide[i % S]), steps, warmup, S)
+    out["i64_narrow_arena"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n, "fused", "i64"), ms), input_sets=S,
+                                   alg_bytes_per_group=alg_bytes_per_group(n, "fused", "i64"),
+                                   log_term_bits=wide[0].log_term_bits,
+                                   note="int64 planes, log-term arena in %d-bit differences from a per-group base term"
+                                        % wide[0].log_term_bits)
+    del wide, whost
     torch.cuda.empty_cache()
 
     # mixed 3-9 peers + 10 % joint consensus, Zipf log lengths; one log arena shared by the sets
