@@ -28,6 +28,11 @@ type ResidentDriver struct {
 	slots  int
 	mixed  bool
 	built  bool
+	// byStart: every leader's log has Raft's own shape (terms never decrease, none above the
+	// leader's term), so the image holds no log arena, only the index where each leader's term
+	// starts and the log's length (rq_round_desc.log_term_start); a log that loses the shape
+	// (the reference appends whatever it is sent, raft.go:158-170) brings the arena back
+	byStart bool
 
 	desc C.rq_round_desc
 	plan *C.rq_plan
@@ -82,6 +87,31 @@ func put32(dst *int32, v int) bool {
 // flattenRow writes group g as one scatter row (4n+7 words, layout of
 // rq_groups_scatter_dev; the last word, the arena offset, is set by the caller)
 // and returns its leader's log terms.
+// logShape measures group g's leader log: shaped (terms never decrease, none above the
+// leader's term), the index of the first entry of the leader's term (or the length), the length.
+func (d *ResidentDriver) logShape(g int) (shaped bool, start int32, length uint32) {
+	l := d.groups[g].Leader
+	if l == nil {
+		return true, 0, 0
+	}
+	shaped, first := true, len(l.log)
+	for i, e := range l.log {
+		if i > 0 && e.TermNum < l.log[i-1].TermNum {
+			shaped = false
+		}
+		if first == len(l.log) && e.TermNum == l.currentTerm {
+			first = i
+		}
+	}
+	if len(l.log) > 0 && l.log[len(l.log)-1].TermNum > l.currentTerm {
+		shaped = false
+	}
+	return shaped, int32(first), uint32(len(l.log))
+}
+
+// WithoutArena reports whether the resident image currently holds no log arena.
+func (d *ResidentDriver) WithoutArena() bool { return d.built && d.byStart }
+
 func (d *ResidentDriver) flattenRow(g int, row []int32) ([]int32, error) {
 	grp, n := d.groups[g], d.slots
 	k := len(grp.Members)
@@ -105,10 +135,12 @@ func (d *ResidentDriver) flattenRow(g int, row []int32) ([]int32, error) {
 				return nil, errRange
 			}
 		}
-		terms = make([]int32, len(l.log))
-		for i, e := range l.log {
-			if !put32(&terms[i], e.TermNum) {
-				return nil, errRange
+		if !d.byStart { // without an arena the log is only measured (logShape), not copied
+			terms = make([]int32, len(l.log))
+			for i, e := range l.log {
+				if !put32(&terms[i], e.TermNum) {
+					return nil, errRange
+				}
 			}
 		}
 	}
@@ -209,6 +241,15 @@ func (d *ResidentDriver) rebuild() error {
 	var arena []int32
 	row := make([]int32, words)
 	d.mixed = false
+	tstart := make([]int32, G)
+	d.byStart = true
+	for g := 0; g < G; g++ {
+		shaped, st, ln := d.logShape(g)
+		tstart[g], length[g] = st, ln
+		if !shaped {
+			d.byStart = false
+		}
+	}
 	for g := 0; g < G; g++ {
 		terms, err := d.flattenRow(g, row)
 		if err != nil {
@@ -222,6 +263,9 @@ func (d *ResidentDriver) rebuild() error {
 		om[g], nm[g] = uint16(uint32(tail[5])), uint16(uint32(tail[5])>>16)
 		if len(d.groups[g].Members) != n {
 			d.mixed = true
+		}
+		if d.byStart {
+			continue
 		}
 		length[g] = uint32(len(terms))
 		d.capacity[g] = sliceCapacity(len(terms))
@@ -237,6 +281,9 @@ func (d *ResidentDriver) rebuild() error {
 	d.arena = d.tail + d.tail/2 + 1<<16
 	if d.arena > math.MaxUint32 {
 		d.arena = math.MaxUint32
+	}
+	if d.byStart {
+		d.arena = 0
 	}
 	arena = append(arena, make([]int32, int(d.arena)-len(arena))...)
 
@@ -256,18 +303,24 @@ func (d *ResidentDriver) rebuild() error {
 	up(&dd.voted_for, vf)
 	up(&dd.voter_last_log_term, ll)
 	up(&dd.commit, commit)
-	up(&dd.leader_term, lterm)
 	up(&dd.cand_term, cterm)
 	up(&dd.cand_id, cid)
-	up(&dd.log_term, arena)
+	if d.byStart {
+		up(&dd.log_term_start, tstart)
+	} else {
+		up(&dd.leader_term, lterm)
+		up(&dd.log_term, arena)
+	}
 	if err != nil {
 		return err
 	}
 	var p unsafe.Pointer
-	if p, err = upload(d, d.off); err != nil {
-		return err
+	if !d.byStart {
+		if p, err = upload(d, d.off); err != nil {
+			return err
+		}
+		dd.log_off = (*C.uint32_t)(p)
 	}
-	dd.log_off = (*C.uint32_t)(p)
 	if p, err = upload(d, length); err != nil {
 		return err
 	}
@@ -385,6 +438,17 @@ func (d *ResidentDriver) Step() error {
 				needRebuild = true
 				break
 			}
+			if d.byStart { // lengths only: no terms travel; the row's last word is the term's start
+				shaped, st, ln := d.logShape(g)
+				if !shaped {
+					needRebuild = true
+					break
+				}
+				row[4*n+6] = st
+				gids[i], roff[i] = int32(g), int32(used)
+				used += int(ln)
+				continue
+			}
 			if len(terms) > int(d.capacity[g]) { // the log outgrew its slice: it moves to free space
 				want := 2*uint64(len(terms)) + 4
 				if d.tail+want > d.arena {
@@ -405,7 +469,11 @@ func (d *ResidentDriver) Step() error {
 		}
 		if !needRebuild {
 			roff[r] = int32(used)
-			bytes := uint64(r*(words+2)+1+used) * 4
+			sent := used
+			if d.byStart {
+				sent = 0
+			}
+			bytes := uint64(r*(words+2)+1+sent) * 4
 			if err := d.check(C.rq_copy_to_device(d.eng.h, d.dIn, d.hIn, C.uint64_t(bytes)), "rq_copy_to_device"); err != nil {
 				return err
 			}

@@ -435,7 +435,10 @@ int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d);
  * the log is written at the row's log_off (the host's choice: the old place if
  * there is room, else free arena space) and log_off[g], log_len[g] are set;
  * without one the row's log_off is ignored and the length must equal the group's
- * slice.  Fields whose
+ * slice.  With log_term_start in the descriptor there is no arena: the row's last
+ * element is the index where the leader's term starts, row_log_off[r+1] -
+ * row_log_off[r] is the log's length (it goes to log_len[g]) and row_log_terms is
+ * not read (may be NULL).  Fields whose
  * descriptor pointer is NULL are skipped.  A row is applied completely or not at
  * all; row_status[r] (may be NULL) = 0, or 1 the log does not fit the group's
  * slice, 2 a term does not fit the arena's entry width, 4 no such group.

@@ -207,12 +207,24 @@ public:
     void MarkDirty(uint32_t group);
     int Step(Report *report = nullptr);      // an RQ_* code; flagged groups as in BatchedDriver::Step
     const std::vector<GroupStatus> &Flagged() const { return flagged_; }
+    // True while the image holds no log arena: every leader's log has Raft's own shape
+    // (terms never decrease, none above the leader's term), so the device only needs the
+    // index where the leader's term starts and the log's length (rq_round_desc.
+    // log_term_start).  A log that loses the shape (the reference appends whatever it is
+    // sent, raft.go:158-170) makes the next Step lay the image out afresh with an arena.
+    bool WithoutArena() const;
     std::vector<Group> &Groups() { return groups_; }
 
 private:
     struct Impl;
     int Rebuild();
-    int FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms) const;
+    struct LogShape {
+        bool shaped = true;      // terms never decrease and none exceeds the leader's term
+        int32_t term_start = 0;  // index of the first entry of the leader's term, or the log's length
+        uint32_t len = 0;
+    };
+    int FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms, LogShape *shape = nullptr) const;
+    LogShape ShapeOf(uint32_t g) const;
     void ApplyRow(uint32_t g, const int32_t *row, uint64_t flags);
     std::vector<Group> groups_;
     uint32_t slots_;

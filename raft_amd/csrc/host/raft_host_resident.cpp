@@ -38,6 +38,7 @@ struct ResidentDriver::Impl {
     // rows actually sent), one coming down (flags, rows); page-locked mirrors of the same size
     char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
     uint64_t *h_cbits = nullptr;
+    bool by_start = false;              // no arena: log_term_start + log_len
 
     int dalloc(uint64_t bytes, void **out) {
         int rc = rq_device_alloc(e, bytes ? bytes : 4, RQ_MEM_DEFAULT, out);
@@ -81,7 +82,27 @@ void ResidentDriver::MarkDirty(uint32_t group) {
 // One group as a scatter row (layout of rq_groups_scatter_dev) plus its leader's
 // log terms.  A group without a leader gets commit = INT32_MAX (N > commit is
 // never true); a group without a candidate gets a term below every voter's.
-int ResidentDriver::FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms) const {
+ResidentDriver::LogShape ResidentDriver::ShapeOf(uint32_t g) const {
+    LogShape s;
+    const Node *l = groups_[g].Leader;
+    if (!l) return s;
+    const std::vector<Entry> &log = l->log;
+    s.len = (uint32_t)log.size();
+    size_t start = log.size();
+    for (size_t i = 0; i < log.size(); i++) {
+        if (i && log[i].TermNum < log[i - 1].TermNum) s.shaped = false;
+        if (start == log.size() && log[i].TermNum == l->currentTerm) start = i;
+    }
+    if (!log.empty() && log.back().TermNum > l->currentTerm) s.shaped = false;
+    s.term_start = (int32_t)start;
+    return s;
+}
+
+bool ResidentDriver::WithoutArena() const { return impl_ && impl_->plan && impl_->by_start; }
+
+// `shape` non-null: the image keeps no arena -- the log is only measured (ShapeOf), its
+// terms are not copied and `terms` stays empty.
+int ResidentDriver::FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms, LogShape *shape) const {
     const Group &grp = groups_[g];
     const uint32_t n = slots_, k = (uint32_t)grp.Members.size();
     if (k < 1 || k > n || n > RQ_MAX_SLOTS) return RQ_E_ARG;
@@ -95,10 +116,13 @@ int ResidentDriver::FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &t
         if (!narrow32(l->commitIndex, tail[0]) || !narrow32(l->currentTerm, tail[1])) return RQ_E_RANGE;
         for (uint32_t p = 0; p < k && p < l->matchIndex.size(); p++)
             if (!narrow32(l->matchIndex[p], match[p])) return RQ_E_RANGE;
-        terms.resize(l->log.size());
-        for (size_t i = 0; i < l->log.size(); i++)
-            if (!narrow32(l->log[i].TermNum, terms[i])) return RQ_E_RANGE;
+        if (!shape) {
+            terms.resize(l->log.size());
+            for (size_t i = 0; i < l->log.size(); i++)
+                if (!narrow32(l->log[i].TermNum, terms[i])) return RQ_E_RANGE;
+        }
     }
+    if (shape) *shape = ShapeOf(g);
     if (const Node *c = grp.Candidate) {
         if (!narrow32(c->currentTerm, tail[2]) || !narrow32(c->id, tail[3])) return RQ_E_RANGE;
     }
@@ -130,23 +154,35 @@ int ResidentDriver::Rebuild() {
     I.off.assign((size_t)G + 1, 0);
     I.cap.assign(G, 0);
     mixed_ = false;
+    // Do all the leaders' logs have Raft's own shape?  Then the device needs no arena.
+    std::vector<int32_t> tstart(G);
+    std::atomic<bool> all_shaped{true};
+    ParallelOverGroups(G, [&](uint32_t g0, uint32_t g1, uint32_t) {
+        for (uint32_t g = g0; g < g1; g++) {
+            const LogShape s = ShapeOf(g);
+            tstart[g] = s.term_start;
+            len[g] = s.len;
+            if (!s.shaped) all_shaped.store(false);
+        }
+    });
+    I.by_start = all_shaped.load();
     // slice capacities from the leaders' log lengths, then the slices' places in the arena
-    for (uint32_t g = 0; g < G; g++) {
-        const Node *l = groups_[g].Leader;
-        I.cap[g] = slice_capacity(l ? l->log.size() : 0);
+    for (uint32_t g = 0; g < G && !I.by_start; g++) {
+        I.cap[g] = slice_capacity(len[g]);
         const uint64_t next = (uint64_t)I.off[g] + I.cap[g];
         if (next > 0xFFFFFFFFull) return RQ_E_RANGE;
         I.off[g + 1] = (uint32_t)next;
     }
-    arena.assign(I.off[G], 0);
+    arena.assign(I.by_start ? 0 : I.off[G], 0);
     // the groups themselves, in parallel (they are independent objects)
     std::atomic<int> err{RQ_OK};
     std::atomic<bool> mixed{false};
     ParallelOverGroups(G, [&](uint32_t g0, uint32_t g1, uint32_t) {
         std::vector<int32_t> row(words), terms;
         for (uint32_t g = g0; g < g1; g++) {
-            int rc = FlattenRow(g, row.data(), terms);
-            if (rc == RQ_OK && terms.size() > I.cap[g]) rc = RQ_E_ARG;
+            LogShape shape;
+            int rc = FlattenRow(g, row.data(), terms, I.by_start ? &shape : nullptr);
+            if (rc == RQ_OK && !I.by_start && terms.size() > I.cap[g]) rc = RQ_E_ARG;
             if (rc != RQ_OK) { err.store(rc); return; }
             for (uint32_t p = 0; p < n; p++) {
                 match[p * ld + g] = row[p]; vt[p * ld + g] = row[n + p];
@@ -156,8 +192,10 @@ int ResidentDriver::Rebuild() {
             commit[g] = tail[0]; lterm[g] = tail[1]; cterm[g] = tail[2]; cid[g] = tail[3];
             om[g] = (uint16_t)((uint32_t)tail[5] & 0xFFFFu); nm[g] = (uint16_t)((uint32_t)tail[5] >> 16);
             if (groups_[g].Members.size() != n) mixed.store(true);
-            len[g] = (uint32_t)terms.size();
-            std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * 4);
+            if (!I.by_start) {
+                len[g] = (uint32_t)terms.size();
+                std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * 4);
+            }
         }
     });
     if (err.load() != RQ_OK) return err.load();
@@ -166,6 +204,7 @@ int ResidentDriver::Rebuild() {
     I.tail = arena.size();
     I.arena_entries = arena.size() + arena.size() / 2 + (1u << 16);
     if (I.arena_entries > 0xFFFFFFFFull) I.arena_entries = 0xFFFFFFFFull;
+    if (I.by_start) I.arena_entries = 0;
     arena.resize(I.arena_entries, 0);
 
     rq_round_desc &d = I.desc;
@@ -185,12 +224,16 @@ int ResidentDriver::Rebuild() {
     RH_TRY(upload(vf.data(), plane * 4, &d.voted_for));
     RH_TRY(upload(ll.data(), plane * 4, &d.voter_last_log_term));
     RH_TRY(upload(commit.data(), (uint64_t)G * 4, &d.commit));
-    RH_TRY(upload(lterm.data(), (uint64_t)G * 4, &d.leader_term));
+    if (!I.by_start) RH_TRY(upload(lterm.data(), (uint64_t)G * 4, &d.leader_term));
     RH_TRY(upload(cterm.data(), (uint64_t)G * 4, &d.cand_term));
     RH_TRY(upload(cid.data(), (uint64_t)G * 4, &d.cand_id));
-    RH_TRY(upload(I.off.data(), ((uint64_t)G + 1) * 4, (const void **)&d.log_off));
     RH_TRY(upload(len.data(), (uint64_t)G * 4, (const void **)&d.log_len));
-    RH_TRY(upload(arena.data(), (uint64_t)arena.size() * 4, &d.log_term));
+    if (I.by_start) {
+        RH_TRY(upload(tstart.data(), (uint64_t)G * 4, &d.log_term_start));
+    } else {
+        RH_TRY(upload(I.off.data(), ((uint64_t)G + 1) * 4, (const void **)&d.log_off));
+        RH_TRY(upload(arena.data(), (uint64_t)arena.size() * 4, &d.log_term));
+    }
     if (mixed_) {
         RH_TRY(upload(om.data(), (uint64_t)G * 2, (const void **)&d.old_mask));
         RH_TRY(upload(nm.data(), (uint64_t)G * 2, (const void **)&d.new_mask));
@@ -210,6 +253,7 @@ int ResidentDriver::Rebuild() {
     I.row_cap = G < kMaxRowsPerTransfer ? G : kMaxRowsPerTransfer;
     const uint64_t nrows = I.row_cap;
     I.term_cap = 64ull * nrows < I.arena_entries ? 64ull * nrows : I.arena_entries;
+    if (I.by_start) I.term_cap = 0;                  // rows carry no terms
     const uint64_t in_bytes = (nrows * (words + 2) + 1 + I.term_cap) * 4, out_bytes = nrows * (8 + (n + 2) * 4);
     RH_TRY(I.dalloc(in_bytes, (void **)&I.d_in));    RH_TRY(I.halloc(in_bytes, &I.h_in));
     RH_TRY(I.dalloc(out_bytes, (void **)&I.d_out));  RH_TRY(I.halloc(out_bytes, &I.h_out));
@@ -261,8 +305,19 @@ int ResidentDriver::Step(Report *report) {
         for (uint32_t i = 0; i < r && !need_rebuild; i++) {
             const uint32_t g = dirty_[i];
             int32_t *row = rows + (size_t)i * words;
-            RH_TRY(FlattenRow(g, row, terms));
+            LogShape shape;
+            RH_TRY(FlattenRow(g, row, terms, I.by_start ? &shape : nullptr));
             if (!mixed_ && groups_[g].Members.size() != n) { need_rebuild = true; break; }
+            if (I.by_start) {
+                // a log that lost Raft's shape needs the arena back: everything is laid out afresh
+                if (!shape.shaped) { need_rebuild = true; break; }
+                row[4 * n + 6] = shape.term_start;
+                gids[i] = g;
+                roff[i] = (uint32_t)used;            // lengths only: no terms travel
+                used += shape.len;
+                if (used > 0xFFFFFFFFull) { need_rebuild = true; break; }
+                continue;
+            }
             if (terms.size() > I.cap[g]) {
                 // the log outgrew its slice: it moves to free space with twice the room;
                 // when that runs out everything is laid out afresh
@@ -281,7 +336,7 @@ int ResidentDriver::Step(Report *report) {
         }
         if (!need_rebuild) {
             roff[r] = (uint32_t)used;
-            const uint64_t bytes = ((uint64_t)r * (words + 2) + 1 + used) * 4;
+            const uint64_t bytes = ((uint64_t)r * (words + 2) + 1 + (I.by_start ? 0 : used)) * 4;
             RH_TRY(rq_copy_to_device(I.e, I.d_in, I.h_in, bytes));
             const char *d = I.d_in;
             RH_TRY(rq_groups_scatter_dev(I.e, nullptr, &I.desc, r, (const uint32_t *)d,

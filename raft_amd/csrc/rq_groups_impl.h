@@ -33,6 +33,9 @@ __device__ __forceinline__ void store_term(void *arena, uint32_t bits, size_t id
 // Words of one scatter row: 4 planes of n slots, then commit, leader_term,
 // cand_term, cand_id, log_base, member masks (old | new << 16), and the arena
 // offset of the group's log (used with a log_len plane: the slice may move).
+// With log_term_start in the round's arguments there is no arena: the last word
+// is the index where the leader's term starts, row_off still gives every row's
+// log length (it goes to log_len) and no terms travel.
 __host__ __device__ constexpr uint32_t scatter_row_words(uint32_t n) { return 4 * n + 7; }
 
 // One wave per row.  The row is checked completely before anything is written,
@@ -50,6 +53,8 @@ __global__ __launch_bounds__(64) void rq_groups_scatter_kernel(rq_round_args_t<T
     uint32_t bad = 0;
     if (g >= a.G) {
         bad = kRowBadGroup;
+    } else if (a.log_term_start) {
+        // nothing to check: no arena
     } else if (a.log_off) {
         const uint32_t len = row_off[r + 1] - row_off[r];
         bool room;
@@ -90,7 +95,12 @@ __global__ __launch_bounds__(64) void rq_groups_scatter_kernel(rq_round_args_t<T
             const_cast<uint16_t *>(a.new_mask)[g] = (uint16_t)(((uint64_t)tail[5] >> 16) & 0xFFFFu);
         }
     }
-    if (a.log_off) {
+    if (a.log_term_start) {
+        if (lane == 0) {
+            const_cast<T *>(a.log_term_start)[g] = row[4 * n + 6];
+            if (a.log_len) const_cast<uint32_t *>(a.log_len)[g] = row_off[r + 1] - row_off[r];
+        }
+    } else if (a.log_off) {
         const uint32_t len = row_off[r + 1] - row_off[r];
         const uint32_t beg = a.log_len ? (uint32_t)row[4 * n + 6] : a.log_off[g];
         if (a.log_len && lane == 0) const_cast<uint32_t *>(a.log_off)[g] = beg;

@@ -57,6 +57,7 @@ def lib():
         l.rh_resident_get_roles.restype = None
         l.rh_resident_mark_dirty.argtypes = [C.c_void_p, C.c_uint32]; l.rh_resident_mark_dirty.restype = None
         l.rh_resident_step.argtypes = [C.c_void_p, u32p]
+        l.rh_resident_without_arena.argtypes = [C.c_void_p]
         l.rh_resident_flagged.argtypes = [C.c_void_p, u32p, u8p, C.c_uint32]
         l.rh_resident_flagged.restype = C.c_uint32
         _l = l
@@ -99,6 +100,10 @@ class Cluster:
         rep = (C.c_uint32 * 3)()
         rc = self.l.rh_resident_step(self.h, rep)
         return rc, dict(uploaded=rep[0], changed=rep[1], rebuilt=bool(rep[2]))
+
+    def without_arena(self):
+        """True while the resident image keeps no log arena (log_term_start + log_len)."""
+        return bool(self.l.rh_resident_without_arena(self.h))
 
     def flagged(self):
         """(group, status) pairs of the last step: conditions that are Go panics in the reference."""

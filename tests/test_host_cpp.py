@@ -77,10 +77,15 @@ def test_append_entries_kats(k):
         c.close()
 
 
-def _build(G, n, seed, term_shift=0):
+def _build(G, n, seed, term_shift=0, raft_shaped=False):
     """A cluster whose object state equals a synthetic batch (every term moved up
-    by term_shift); returns (cluster, batch) -- the batch is returned unshifted."""
+    by term_shift); returns (cluster, batch) -- the batch is returned unshifted.
+    raft_shaped: no log term above its leader's term (synth.raft_valid)."""
     b = synth.gen_fused(G, n, seed=seed)
+    if raft_shaped:
+        b = synth.raft_valid(b)
+        # a candidate that wins leads with its own log: none of its terms above its term either
+        b["last_log_term"] = np.minimum(b["last_log_term"], b["cand_term"][None, :]).astype(np.int32)
     c = h.Cluster(G, n)
     if term_shift:
         c0, b0 = c, b
@@ -532,6 +537,64 @@ def test_resident_driver_tracks_the_oracle_over_incremental_steps():
                 if lead >= 0:
                     assert c.get(g, lead)["commitIndex"] == exp.commit[g], (it, g)
             for g in range(G):                                      # keep the batched driver's roles (used by flatten) in step
+                lead, cand = c.get_roles(g)
+                c.l.rh_group_roles(c.h, g, lead, cand)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_resident_driver_without_a_log_arena():
+    """All leaders' logs have Raft's own shape (terms never decrease, none above the
+    leader's term): the resident image holds no log arena, only the index where each
+    leader's term starts and the log's length, and touched groups travel without their
+    terms.  The objects must still end where the oracle (which looks terms up) puts
+    them.  A log that loses the shape brings the arena back at the next step."""
+    G, n = 1500, 5
+    c, b = _build(G, n, seed=43, raft_shaped=True)
+    rng = np.random.default_rng(11)
+    try:
+        c.use_resident(0)
+        for g in range(G):
+            c.roles(g, *c.get_roles(g))
+        for it in range(5):
+            if it:
+                touched = rng.choice(G, 200, replace=False)
+                for j, g in enumerate(touched.tolist()):
+                    lead, cand = c.get_roles(g)
+                    if lead >= 0:
+                        s = c.get(g, lead)
+                        grow = 200 if (it == 2 and j < 5) else int(rng.integers(0, 4))
+                        new_len = s["logLen"] + grow
+                        terms = [1 + (i * int(s["currentTerm"])) // new_len for i in range(new_len)]   # 1 .. currentTerm
+                        if it == 4 and j == 0:
+                            terms[0] = terms[-1] + 5          # a log no Raft leader would hold: decreasing terms
+                        c.seed(g, lead, s["currentTerm"], s["votedFor"], h.LEADER, s["commitIndex"], terms)
+                        c.set_match(g, lead, [int(x) for x in rng.integers(0, new_len + 2, n)])    # some beyond the log
+                    if cand >= 0:
+                        s = c.get(g, cand)
+                        c.seed(g, cand, s["currentTerm"] + int(rng.integers(0, 2)), s["votedFor"], h.CANDIDATE, s["commitIndex"])
+            rc, f = c.flatten(log_cap=1 << 22)
+            assert rc == 0
+            exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                                f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
+            roles_before = [c.get_roles(g) for g in range(G)]
+            rc, rep = c.step_resident()
+            assert rc == 0
+            assert rep["rebuilt"] == (it in (0, 4))               # first image; the log that lost the shape
+            assert c.without_arena() == (it < 4)
+            moved = (exp.commit != f["commit"]) | (exp.stepdown_mask != 0) | (exp.elected != 0) | (exp.status != 0)
+            assert rep["changed"] == int(moved.sum())
+            assert sorted(c.flagged()) == sorted((int(g), int(exp.status[g])) for g in np.nonzero(exp.status)[0])
+            for g in range(G):
+                lead, cand = roles_before[g]
+                if cand >= 0:
+                    for p in range(n):
+                        assert c.get(g, p)["currentTerm"] == exp.voter_term[p, g], (it, g, p)
+                    assert (c.get_roles(g)[0] == cand) == bool(exp.elected[g]), (it, g)
+                if lead >= 0:
+                    assert c.get(g, lead)["commitIndex"] == exp.commit[g], (it, g)
+            for g in range(G):
                 lead, cand = c.get_roles(g)
                 c.l.rh_group_roles(c.h, g, lead, cand)
     finally:
