@@ -120,7 +120,7 @@ def parse():
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
     ap.add_argument("--no-status", action="store_true", help="skip the per-group status byte output")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
-    ap.add_argument("--preheat-rotations", type=int, default=8,
+    ap.add_argument("--preheat-rotations", type=int, default=32,
                     help="untimed passes over all input sets before --warmup (the first builds every "
                          "prepared launch and touches every buffer)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
