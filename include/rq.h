@@ -403,7 +403,18 @@ int rq_plan_destroy(rq_plan *p);
  *   flog_term_base  [G] or NULL: added to the entries of all followers of group g;
  *   flog_base       [n][ld] or NULL: follower s keeps only log[flog_base[s] ...]
  *                   on the device (the suffix around nextIndex is all a
- *                   consistency check can ask for). */
+ *                   consistency check can ask for);
+ *   tile_bytes / out_tile_bytes   0: slot-major planes, and flog_off is a CSR over
+ *                   slot ids s = p * ld + g as in rq_append_check.  Else the 64-group
+ *                   tiles of rq_round_desc, so that one resident image serves rounds
+ *                   and replication (follower_term IS the round's voter_term array,
+ *                   match_index_io its match array): the inputs and the arrays updated
+ *                   in place are addressed with tile_bytes, the pure outputs
+ *                   (success_mask, stepdown_mask, status_out, and follower_term_out
+ *                   unless it is follower_term itself) with out_tile_bytes; ld is
+ *                   ignored; flog_off is per slot, element (p, g) the start of follower
+ *                   (p, g)'s log and element (p, g + 1) its end, g = 0 .. G (tile G / 64
+ *                   must exist). */
 typedef struct rq_append_desc {
     uint32_t struct_size;       /* sizeof(rq_append_desc) */
     uint32_t layout;            /* RQ_LAYOUT_I32 or RQ_LAYOUT_I64 */
@@ -418,6 +429,7 @@ typedef struct rq_append_desc {
     uint16_t *success_mask, *stepdown_mask;
     void *match_index_io, *next_index_io;
     uint8_t *status_out;
+    uint64_t tile_bytes, out_tile_bytes;
 } rq_append_desc;
 int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d);
 

@@ -23,16 +23,25 @@ namespace {
 // ---------------------------------------------------------------------------
 // NMAX = compile-time slot bound (the loop over slots is fully unrolled so that
 // every plane load of a group is in flight before the first gather).
-template <int NMAX, typename T>
+// Index of element (p, g) of an array of P: planes field[p * ld + g], or (TILED) the round
+// kernels' 64-group tiles, whose stride is a multiple of 8 bytes and so of every element size.
+template <bool TILED, typename P>
+__device__ __forceinline__ size_t append_index(uint64_t tile_bytes, size_t ld, uint32_t g, uint32_t p) {
+    if constexpr (TILED) return (size_t)(g >> 6) * (size_t)(tile_bytes / sizeof(P)) + (size_t)(p * 64u + (g & 63u));
+    else return (size_t)p * ld + g;
+}
+
+template <int NMAX, bool TILED, typename T>
 __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_t<T> a) {
     typedef typename std::make_unsigned<T>::type U;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.G) return;
     const size_t ld = a.ld;
     const uint32_t n = a.n;
-    const T lt = __builtin_nontemporal_load(a.leader_term + g);
-    const T tbase = a.flog_term_base ? __builtin_nontemporal_load(a.flog_term_base + g) : (T)0;
-    uint32_t act = a.active_mask ? (uint32_t)a.active_mask[g] : 0xFFFFu;
+    const size_t gT = append_index<TILED, T>(a.tile_bytes, ld, g, 0);
+    const T lt = __builtin_nontemporal_load(a.leader_term + gT);
+    const T tbase = a.flog_term_base ? __builtin_nontemporal_load(a.flog_term_base + gT) : (T)0;
+    uint32_t act = a.active_mask ? (uint32_t)a.active_mask[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)] : 0xFFFFu;
     act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
     const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
     T ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX], fb[NMAX];
@@ -41,12 +50,14 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     for (int p = 0; p < NMAX; p++) {
         ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = fb[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
         if ((act >> p) & 1u) {
-            const size_t s = p * ld + g;
+            const size_t s = append_index<TILED, T>(a.tile_bytes, ld, g, p);
+            const size_t so = append_index<TILED, uint32_t>(a.tile_bytes, ld, g, p);
             ft[p] = __builtin_nontemporal_load(a.follower_term + s);
             pi[p] = __builtin_nontemporal_load(a.prev_log_index + s);
             pt[p] = __builtin_nontemporal_load(a.prev_log_term + s);
-            o0[p] = __builtin_nontemporal_load(a.flog_off + s);
-            o1[p] = a.flog_off[s + 1];
+            o0[p] = __builtin_nontemporal_load(a.flog_off + so);
+            // the end of the log = the next entry: plain load, the neighbour's line is already on its way
+            o1[p] = TILED ? a.flog_off[append_index<TILED, uint32_t>(a.tile_bytes, ld, g + 1, p)] : a.flog_off[so + 1];
             if (a.flog_base) fb[p] = __builtin_nontemporal_load(a.flog_base + s);
             if (a.n_new) nn[p] = __builtin_nontemporal_load(a.n_new + s);
             if (a.match_index_io) mi[p] = __builtin_nontemporal_load(a.match_index_io + s);
@@ -68,17 +79,20 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
         if (r && in)
             tg[p] = (T)((U)load_term<true, T>(a.flog_term, a.flog_term_bits, (size_t)o0[p] + (size_t)wi) + (U)tbase);
     }
+    // pure outputs live in their own tile block; follower terms updated in place stay with the inputs
+    const uint64_t out_tile = a.out_tile_bytes;
+    const uint64_t fo_tile = (const void *)a.follower_term_out == (const void *)a.follower_term ? a.tile_bytes : out_tile;
     uint32_t ok = 0, sd = 0, st = bad ? kStBadCsr : 0;
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
         if (!((act >> p) & 1u)) continue;
-        const size_t s = p * ld + g;
+        const size_t s = append_index<TILED, T>(a.tile_bytes, ld, g, p);
         const bool r = (reach >> p) & 1u, in = (inb >> p) & 1u;
         const bool success = r && in && tg[p] == pt[p];
         sd |= (uint32_t)(lt > ft[p]) << p;
         ok |= (uint32_t)success << p;
         st |= (r && !in) ? kStLogOob : 0;
-        __builtin_nontemporal_store(tmax(ft[p], lt), a.follower_term_out + s);
+        __builtin_nontemporal_store(tmax(ft[p], lt), a.follower_term_out + append_index<TILED, T>(fo_tile, ld, g, p));
         if (upd) {
             T m2 = mi[p], n2 = ni[p];
             if (success) { m2 = (T)((U)pi[p] + (U)nn[p]); n2 = (T)((U)m2 + (U)1); }
@@ -87,9 +101,10 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
             if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
         }
     }
-    __builtin_nontemporal_store((uint16_t)ok, a.success_mask + g);
-    __builtin_nontemporal_store((uint16_t)sd, a.stepdown_mask + g);
-    if (a.status_out) a.status_out[g] = (uint8_t)st;
+    const size_t g16 = append_index<TILED, uint16_t>(out_tile, ld, g, 0);
+    __builtin_nontemporal_store((uint16_t)ok, a.success_mask + g16);
+    __builtin_nontemporal_store((uint16_t)sd, a.stepdown_mask + g16);
+    if (a.status_out) a.status_out[append_index<TILED, uint8_t>(out_tile, ld, g, 0)] = (uint8_t)st;
 }
 
 // raft.go:172-176 elementwise
@@ -120,23 +135,26 @@ __global__ __launch_bounds__(kBlock) void rq_follower_clamp_kernel(
 template <typename T>
 hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, hipStream_t stream) {
     if (a.G == 0) return hipSuccess;
-    if (a.G > 0x7FFFFFFFu || a.ld < a.G || a.n < 1 || a.n > 16) return hipErrorInvalidValue;
+    if (a.G > 0x7FFFFFFFu || (a.ld < a.G && !a.tile_bytes) || a.n < 1 || a.n > 16) return hipErrorInvalidValue;
+    if ((a.tile_bytes & 7u) || (a.out_tile_bytes & 7u) || ((a.tile_bytes != 0) != (a.out_tile_bytes != 0))) return hipErrorInvalidValue;
     const uint32_t tb = a.flog_term_bits;
     if (tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
     const uint32_t block = 128;
     const dim3 grid((a.G + block - 1) / block), blk(block);
+#define RQ_APPEND_CASE(N)                                                                                   \
+    case N:                                                                                                 \
+        if (a.tile_bytes) hipLaunchKernelGGL((rq_append_check_kernel<N, true, T>), grid, blk, 0, stream, a); \
+        else hipLaunchKernelGGL((rq_append_check_kernel<N, false, T>), grid, blk, 0, stream, a);            \
+        break;
     switch (a.n) {
-    case 1: hipLaunchKernelGGL((rq_append_check_kernel<1, T>), grid, blk, 0, stream, a); break;
-    case 2: hipLaunchKernelGGL((rq_append_check_kernel<2, T>), grid, blk, 0, stream, a); break;
-    case 3: hipLaunchKernelGGL((rq_append_check_kernel<3, T>), grid, blk, 0, stream, a); break;
-    case 4: hipLaunchKernelGGL((rq_append_check_kernel<4, T>), grid, blk, 0, stream, a); break;
-    case 5: hipLaunchKernelGGL((rq_append_check_kernel<5, T>), grid, blk, 0, stream, a); break;
-    case 6: hipLaunchKernelGGL((rq_append_check_kernel<6, T>), grid, blk, 0, stream, a); break;
-    case 7: hipLaunchKernelGGL((rq_append_check_kernel<7, T>), grid, blk, 0, stream, a); break;
-    case 8: hipLaunchKernelGGL((rq_append_check_kernel<8, T>), grid, blk, 0, stream, a); break;
-    case 9: hipLaunchKernelGGL((rq_append_check_kernel<9, T>), grid, blk, 0, stream, a); break;
-    default: hipLaunchKernelGGL((rq_append_check_kernel<16, T>), grid, blk, 0, stream, a); break;
+    RQ_APPEND_CASE(1) RQ_APPEND_CASE(2) RQ_APPEND_CASE(3) RQ_APPEND_CASE(4) RQ_APPEND_CASE(5)
+    RQ_APPEND_CASE(6) RQ_APPEND_CASE(7) RQ_APPEND_CASE(8) RQ_APPEND_CASE(9)
+    default:
+        if (a.tile_bytes) hipLaunchKernelGGL((rq_append_check_kernel<16, true, T>), grid, blk, 0, stream, a);
+        else hipLaunchKernelGGL((rq_append_check_kernel<16, false, T>), grid, blk, 0, stream, a);
+        break;
     }
+#undef RQ_APPEND_CASE
     return hipGetLastError();
 }
 

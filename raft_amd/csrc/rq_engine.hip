@@ -387,7 +387,8 @@ int follower_clamp_host(rq_engine *e, uint64_t count, const T *leader_commit, co
 
 template <typename T>
 int append_args_ok(const rq_append_args_t<T> &a) {
-    if (a.n < 1 || a.n > RQ_MAX_SLOTS || a.ld < a.G) return RQ_E_ARG;
+    if (a.n < 1 || a.n > RQ_MAX_SLOTS || (a.ld < a.G && !a.tile_bytes)) return RQ_E_ARG;
+    if ((a.tile_bytes & 7u) || (a.out_tile_bytes & 7u) || ((a.tile_bytes != 0) != (a.out_tile_bytes != 0))) return RQ_E_ARG;
     if (!a.follower_term || !a.leader_term || !a.prev_log_index || !a.prev_log_term ||
         !a.flog_off || !a.flog_term || !a.follower_term_out || !a.success_mask || !a.stepdown_mask)
         return RQ_E_ARG;
@@ -477,6 +478,7 @@ int append_check_dev(rq_engine *e, void *stream, const rq_append_desc &d) {
     a.follower_term_out = (T *)d.follower_term_out; a.success_mask = d.success_mask;
     a.stepdown_mask = d.stepdown_mask; a.match_index_io = (T *)d.match_index_io;
     a.next_index_io = (T *)d.next_index_io; a.status_out = d.status_out;
+    a.tile_bytes = d.tile_bytes; a.out_tile_bytes = d.out_tile_bytes;
     if (a.flog_term_bits > 8 * sizeof(T) || d.flog_terms > 0xFFFFFFFFull) return RQ_E_ARG;
     if (!a.flog_term && d.flog_terms == 0) a.flog_term = a.flog_off;   // empty arena: never dereferenced
     RQ_TRY(append_args_ok(a));

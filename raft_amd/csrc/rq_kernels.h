@@ -114,6 +114,13 @@ struct rq_append_args_t {
     T *match_index_io;              // [n][ld], may be null
     T *next_index_io;               // [n][ld], may be null
     uint8_t  *status_out;           // [G], may be null
+    // 0 = slot-major planes and a CSR over slot ids s = p * ld + g.  Else the 64-group tiles of
+    // the round kernels (rq_round_args_t): tile_bytes is the stride of the block that holds the
+    // inputs and the arrays updated in place, out_tile_bytes that of the pure outputs
+    // (success_mask, stepdown_mask, status_out, and follower_term_out unless it IS follower_term);
+    // flog_off then is per slot: element (p, g) is the start of follower (p, g)'s log and
+    // element (p, g + 1) its end, g = 0 .. G.
+    uint64_t tile_bytes, out_tile_bytes;
 };
 typedef rq_append_args_t<int32_t> rq_append_args;
 typedef rq_append_args_t<int64_t> rq_append64_args;

@@ -76,6 +76,94 @@ def encode_log_terms(log_term, log_off=None, bits=0, per_group_base=False):
     return v.astype(dt), bits, base
 
 
+class TiledAppendBatch:
+    """An AppendEntries batch (synth.gen_append: planes [n][ld], follower-log CSR over slot
+    ids) on the device in the 64-group tiles of rq_append_desc.tile_bytes: one block for the
+    inputs and the arrays updated in place, one for the pure outputs.  .t maps the C-ABI names
+    to views that start at each array's place inside tile 0 (what the descriptor's pointers
+    name), for DeviceEngine.append_check; fetch(name) returns an array as [slots][G] / [G]."""
+
+    def __init__(self, b, device="cuda:0", term_bits=0, in_place_terms=True, extra_in=None, extra_out=None):
+        """extra_in: {name: host array [G] or [slots][G]} and extra_out: [(name, slots, numpy dtype)]
+        -- further arrays laid into the same two blocks, e.g. the commit round's commit /
+        log_off / commit_out, so that ONE resident image serves replication and rounds
+        (the round's descriptor then names match_index as its match array)."""
+        G, n, ld = int(b["G"]), int(b["n"]), int(b["ld"])
+        self.G, self.n = G, n
+        self.device = torch.device(device)
+        vdt = np.asarray(b["follower_term"]).dtype
+        ntiles = (G + 1 + 63) // 64                      # the per-slot offsets have G + 1 entries
+        off = np.asarray(b["flog_off"]).astype(np.int64)
+        off_ps = np.stack([off[p * ld: p * ld + G + 1] for p in range(n)]).astype(np.uint32).view(np.int32)
+        ins = [(k, n, np.asarray(b[k])[:, :G]) for k in ("follower_term", "prev_log_index", "prev_log_term", "n_new",
+                                                      "match_index", "next_index") if k in b]
+        if "flog_base" in b:
+            ins.append(("flog_base", n, np.asarray(b["flog_base"])[:, :G]))
+        ins.append(("flog_off", n, off_ps))
+        ins.append(("leader_term", 1, np.asarray(b["leader_term"])[None, :G]))
+        if "active_mask" in b:
+            ins.append(("active_mask", 1, np.asarray(b["active_mask"]).view(np.int16)[None, :G]))
+        if "flog_term_base" in b:
+            ins.append(("flog_term_base", 1, np.asarray(b["flog_term_base"])[None, :G]))
+        for k, a in (extra_in or {}).items():
+            a = np.asarray(a)
+            ins.append((k, a.shape[0] if a.ndim == 2 else 1, a.reshape(a.shape[0] if a.ndim == 2 else 1, -1)))
+        outs = [("success_mask", 1, np.dtype(np.int16)), ("stepdown_mask", 1, np.dtype(np.int16)),
+                ("status", 1, np.dtype(np.uint8))] + [(k, sl, np.dtype(dt)) for k, sl, dt in (extra_out or [])]
+        if not in_place_terms:
+            outs.insert(0, ("follower_term_out", n, np.dtype(vdt)))
+        ins.sort(key=lambda f: -f[2].dtype.itemsize)
+        outs.sort(key=lambda f: -f[2].itemsize)
+        self._place, pos = {}, 0
+        for k, slots, a in ins:
+            self._place[k] = (False, pos, slots, a.dtype)
+            pos += slots * 64 * a.dtype.itemsize
+        self.tile_bytes = (pos + 255) // 256 * 256
+        pos = 0
+        for k, slots, dt in outs:
+            self._place[k] = (True, pos, slots, dt)
+            pos += slots * 64 * dt.itemsize
+        self.out_tile_bytes = (pos + 255) // 256 * 256
+        block = np.zeros((ntiles, self.tile_bytes), np.uint8)
+        for k, slots, a in ins:
+            o = self._place[k][1]
+            pad = np.zeros((slots, ntiles * 64), a.dtype)
+            cols = min(a.shape[1], ntiles * 64)
+            pad[:, :cols] = a[:, :cols]
+            view = block[:, o: o + slots * 64 * a.dtype.itemsize].view(a.dtype).reshape(ntiles, slots, 64)
+            view[...] = pad.reshape(slots, ntiles, 64).transpose(1, 0, 2)
+        self._in = torch.from_numpy(block.reshape(-1)).to(self.device)
+        oblock = np.zeros((ntiles, self.out_tile_bytes), np.uint8)
+        if not in_place_terms:
+            # slots that receive no RPC are not written by the batch: they keep the follower's term
+            ft = np.asarray(b["follower_term"])[:, :G]
+            o = self._place["follower_term_out"][1]
+            pad = np.zeros((n, ntiles * 64), ft.dtype)
+            pad[:, :G] = ft
+            view = oblock[:, o: o + n * 64 * ft.dtype.itemsize].view(ft.dtype).reshape(ntiles, n, 64)
+            view[...] = pad.reshape(n, ntiles, 64).transpose(1, 0, 2)
+        self._out = torch.from_numpy(oblock.reshape(-1)).to(self.device)
+        enc, self.term_bits, _ = encode_log_terms(b["flog_term"], bits=term_bits)
+        if enc.size == 0:
+            enc = np.zeros(1, enc.dtype)
+        self.flog_terms = int(np.asarray(b["flog_term"]).size)
+        self.t = {k: (self._out if is_out else self._in)[o:] for k, (is_out, o, _, _) in self._place.items()}
+        self.t["flog_term"] = torch.from_numpy(enc).to(self.device)
+        if in_place_terms:
+            self.t["follower_term_out"] = self.t["follower_term"]
+            self._place["follower_term_out"] = self._place["follower_term"]
+        self.t["_tile_bytes"], self.t["_out_tile_bytes"] = self.tile_bytes, self.out_tile_bytes
+        self.wide = vdt == np.int64
+
+    def fetch(self, name):
+        is_out, o, slots, dt = self._place[name]
+        torch.cuda.synchronize(self.device)
+        blk = (self._out if is_out else self._in).cpu().numpy().reshape(-1, self.out_tile_bytes if is_out else self.tile_bytes)
+        v = blk[:, o: o + slots * 64 * dt.itemsize].view(dt).reshape(blk.shape[0], slots, 64)
+        a = v.transpose(1, 0, 2).reshape(slots, -1)[:, : self.G]
+        return a.copy() if slots > 1 else a[0].copy()
+
+
 class DeviceBatch:
     """One batch of groups uploaded to a GPU plus its output buffers."""
 
@@ -427,19 +515,20 @@ class DeviceEngine:
         assert b.wide
         return self.round(b, what, variant, want_bits, status)
 
-    def append_check(self, t, G, n, ld, flog_term_bits=0, flog_terms=None):
+    def append_check(self, t, G, n, ld, flog_term_bits=0, flog_terms=None, wide=None):
         """Enqueue the AppendEntries consistency batch on device tensors
         (rq_append_check_dev; int32 or int64 planes).  t: dict of tensors with the C-ABI
         names; active_mask, n_new, match_index, next_index, status, flog_base and
         flog_term_base may be absent.  follower_term_out may be the follower_term tensor
         itself (in-place terms); match_index / next_index are updated in place.
         flog_term_bits: entry width of the flog_term tensor (0 = the planes' element)."""
-        wide = t["follower_term"].dtype == torch.int64
+        wide = t["follower_term"].dtype == torch.int64 if wide is None else wide
         p = lambda k: t[k].data_ptr() if t.get(k) is not None else None
         d = AppendDesc()
         d.struct_size = C.sizeof(AppendDesc)
         d.layout = LAYOUT_I64 if wide else LAYOUT_I32
         d.G, d.n, d.ld = G, n, ld
+        d.tile_bytes, d.out_tile_bytes = t.get("_tile_bytes", 0), t.get("_out_tile_bytes", 0)
         d.flog_term_bits = flog_term_bits
         d.flog_terms = t["flog_term"].numel() if flog_terms is None else flog_terms
         d.active_mask = p("active_mask")

@@ -1465,3 +1465,84 @@ def test_term_start_instead_of_the_arena_lookup(dev, kind, tiled):
     only = DeviceBatch(b, term_start=True, tiled=tiled)
     dev.commit_advance(only)
     assert np.array_equal(only.results()["commit"], exp["commit"])
+
+
+@pytest.mark.parametrize("n", [1, 3, 4, 5, 9, 16])
+def test_append_check_on_tiles(dev, n):
+    """The AppendEntries batch on the 64-group tiles of the round kernels
+    (rq_append_desc.tile_bytes): per-slot follower-log offsets, inputs and in-place arrays
+    in one block, pure outputs in another; ragged last tiles, inactive slots, adversarial
+    indices, windows and narrow arenas -- against the oracle on the same batch in planes."""
+    from raft_amd.device import TiledAppendBatch
+    for G, ld in ((1, 1), (63, 63), (64, 70), (65, 65), (5000, 5000), (30011, 30080)):
+        for adv in (False, True):
+            b = synth.gen_append(G, n, seed=11 * n + G, ld=ld, adversarial=adv)
+            args, kw = _append_args(b)
+            exp = o.append_check(*args, **kw)
+            for variant in range(3):
+                bb, term_bits, in_place = b, 32, True
+                if variant == 1:
+                    bb, term_bits, in_place = synth.window_flogs(b), 0, False    # windowed logs, narrowest entries
+                elif variant == 2:
+                    term_bits = 0
+                tb = TiledAppendBatch(bb, term_bits=term_bits, in_place_terms=in_place)
+                dev.append_check(tb.t, G, n, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=tb.wide)
+                case = (n, G, adv, variant)
+                assert np.array_equal(tb.fetch("follower_term_out").reshape(n, G), exp["follower_term"][:, :G]), case
+                assert np.array_equal(tb.fetch("success_mask").view(np.uint16), exp["success_mask"][:G]), case
+                assert np.array_equal(tb.fetch("stepdown_mask").view(np.uint16), exp["stepdown_mask"][:G]), case
+                assert np.array_equal(tb.fetch("status"), exp["status"][:G]), case
+                assert np.array_equal(tb.fetch("match_index").reshape(n, G), exp["match_index"][:, :G]), case
+                assert np.array_equal(tb.fetch("next_index").reshape(n, G), exp["next_index"][:, :G]), case
+    # the wide layout on tiles
+    b = synth.gen_append(20011, n, seed=5 + n, adversarial=True)
+    w = synth.Batch(b)
+    for k in ("follower_term", "leader_term", "prev_log_term", "flog_term"):
+        w[k] = b[k].astype(np.int64) + (1 << 40)
+    for k in ("prev_log_index", "n_new", "match_index", "next_index"):
+        w[k] = b[k].astype(np.int64)
+    args, kw = _append_args(w)
+    exp = o.append_check64(*args, **kw)
+    tb = TiledAppendBatch(w, term_bits=64)
+    assert tb.wide
+    dev.append_check(tb.t, w.G, n, w.G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=True)
+    assert np.array_equal(tb.fetch("follower_term_out").reshape(n, -1), exp["follower_term"])
+    assert np.array_equal(tb.fetch("success_mask").view(np.uint16), exp["success_mask"])
+    assert np.array_equal(tb.fetch("match_index").reshape(n, -1), exp["match_index"])
+    assert np.array_equal(tb.fetch("status"), exp["status"])
+
+
+def test_replicate_then_commit_on_one_tiled_image(dev):
+    """One resident image in 64-group tiles serves both steps: the AppendEntries batch
+    updates matchIndex inside the tiles, and the commit round reads that same array as its
+    `match` (its commit, leader term, log offsets and output sit in the same two blocks).
+    Replicate -> match -> commit without a byte leaving the device; against the oracle."""
+    import ctypes as C
+    import torch
+    from raft_amd import _lib
+    from raft_amd.device import TiledAppendBatch, encode_log_terms
+    G, n = 50003, 5
+    b = synth.gen_append(G, n, seed=97)
+    c = synth.gen_fused(G, n, seed=6)                       # the leaders' commitIndex, terms and logs
+    args, kw = _append_args(b)
+    exp_a = o.append_check(*args, **kw)
+    exp_c, exp_st = o.commit_advance(exp_a["match_index"], c.commit, b.leader_term, c.log_off, c.log_term)
+    tb = TiledAppendBatch(b, extra_in=dict(commit=c.commit, log_off=c.log_off.view(np.int32)),
+                          extra_out=[("commit_out", 1, np.int32), ("round_status", 1, np.uint8)])
+    arena, bits, _ = encode_log_terms(c.log_term, bits=0)
+    log_term = torch.from_numpy(arena).to("cuda:0")
+    dev.append_check(tb.t, G, n, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=False)
+    d = _lib.RoundDesc()
+    d.struct_size = C.sizeof(_lib.RoundDesc)
+    d.layout, d.what, d.G, d.n = 4, 1, G, n
+    d.tile_bytes, d.out_tile_bytes = tb.tile_bytes, tb.out_tile_bytes
+    d.match = tb.t["match_index"].data_ptr()                # the array the batch above just updated
+    d.commit, d.leader_term = tb.t["commit"].data_ptr(), tb.t["leader_term"].data_ptr()
+    d.log_off, d.log_term = tb.t["log_off"].data_ptr(), log_term.data_ptr()
+    d.log_terms, d.log_term_bits = int(c.log_term.size), bits
+    d.commit_out, d.status_out = tb.t["commit_out"].data_ptr(), tb.t["round_status"].data_ptr()
+    rc = dev._l.rq_round_dev(dev._h, torch.cuda.current_stream().cuda_stream, C.byref(d))
+    assert rc == 0
+    assert np.array_equal(tb.fetch("match_index"), exp_a["match_index"][:, :G])
+    assert np.array_equal(tb.fetch("commit_out"), exp_c) and np.array_equal(tb.fetch("round_status"), exp_st)
+    assert (exp_c != c.commit).mean() > 0.01 and (exp_st != 0).any()

@@ -2,7 +2,7 @@
 """The AppendEntries consistency batch alone, for profiling: 1M groups x 4 follower
 planes (no mask), 8-bit follower-log entries, 6 rotating sets, device-resident.
 
-    python tools/append_probe.py [launches=120] [term_bits=0]
+    python tools/append_probe.py [launches=120] [term_bits=0] [tiles|planes]
 Prints microseconds per launch and the fraction of HBM peak (186 algorithmic
 bytes per group)."""
 import os
@@ -15,15 +15,22 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from raft_amd import synth
-from raft_amd.device import DeviceEngine, encode_log_terms
+from raft_amd.device import DeviceEngine, TiledAppendBatch, encode_log_terms
 
 launches = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 term_bits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+tiled = not (len(sys.argv) > 3 and sys.argv[3] == "planes")
 G, n, dev = 1 << 20, 4, torch.device("cuda", 0)
 eng = DeviceEngine(0)
 sets = []
 for s in range(6):
     b = synth.gen_append(G, n, seed=900 + s)
+    if tiled:
+        del b["active_mask"]                       # n follower planes, no mask
+        tb = TiledAppendBatch(b, dev, term_bits=term_bits)
+        tb.t["_bits"], tb.t["_terms"], tb.t["_keep"] = tb.term_bits, tb.flog_terms, tb
+        sets.append(tb.t)
+        continue
     enc, bits, _ = encode_log_terms(b.flog_term, bits=term_bits)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     t = {k: up(b[k]) for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
@@ -40,7 +47,7 @@ for s in range(6):
 
 def launch(i):
     t = sets[i % len(sets)]
-    eng.append_check(t, G, n, G, flog_term_bits=t["_bits"], flog_terms=t["_terms"])
+    eng.append_check(t, G, n, G, flog_term_bits=t["_bits"], flog_terms=t["_terms"], wide=False)
 
 
 for i in range(12):
@@ -54,6 +61,6 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / launches * 1e3
 alg = 44 * 4 + 4 + 2 + 2 + 2
-print("append_check 1M x 4 followers, %d-bit entries: %.2f us per launch, %.1f %% of 8 TB/s (186 B per group)"
-      % (sets[0]["_bits"], us, 100 * alg * G / (us * 1e-6) / 8e12))
+print("append_check 1M x 4 followers, %s, %d-bit entries: %.2f us per launch, %.1f %% of 8 TB/s (186 B per group)"
+      % ("64-group tiles" if tiled else "planes", sets[0]["_bits"], us, 100 * alg * G / (us * 1e-6) / 8e12))
 eng.close()
