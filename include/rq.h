@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RQ_VERSION 0x000201 /* 0.2.1: rq_round_desc gained start_signal and log_term_start */
+#define RQ_VERSION 0x000202 /* 0.2.2: rq_round_desc gained start_signal and log_term_start, rq_append_desc the tile strides */
 
 /* return codes */
 #define RQ_OK            0
