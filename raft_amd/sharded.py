@@ -122,7 +122,11 @@ class SummaryExchange:
                 if self._l.rq_device_alloc(h, 8, 3, C.byref(p)) != 0:      # RQ_MEM_SIGNAL
                     break
                 self._signals.append(p.value)
-            if len(self._signals) < depth:          # no signal memory on this device: event fences
+            # a wait that is satisfied at once: does this stack take stream waits on signal memory at all?
+            if len(self._signals) == depth and self._l.rq_stream_wait_signal(h, self._side.cuda_stream,
+                                                                             self._signals[0], 0) != 0:
+                self._l.rq_device_free(h, self._signals.pop())
+            if len(self._signals) < depth:          # no signal memory / stream waits on this device: event fences
                 for p in self._signals:
                     self._l.rq_device_free(h, p)
                 self._l.rq_engine_destroy(h)
