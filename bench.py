@@ -221,6 +221,28 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
                             note="log-term arena kept as int32 entries")
     del sets
     torch.cuda.empty_cache()
+    # Independent rounds on several streams: launches on ONE stream run strictly one after the
+    # other (a 1M-group launch spends ~2 us ramping up and draining: 8M groups in one launch run
+    # at 74 %); the same rounds dealt to three streams overlap one launch's end with the next
+    # one's start.  Effective time per round by the host clock -- single launches take longer.
+    sets = [DeviceBatch(b, device, log_term_bits=args.log_term_bits, tiled=tiled) for b in host_batches]
+    streams3 = [torch.cuda.Stream(device=device) for _ in range(3)]
+
+    def dealt(count):
+        for i in range(count):
+            with torch.cuda.stream(streams3[i % 3]):
+                eng.fused_round(sets[i % S])
+    dealt(2 * S)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    dealt(240)
+    torch.cuda.synchronize(device)
+    ms = (time.perf_counter() - t0) / 240 * 1e3
+    out["three_streams"] = dict(ms_per_round=ms, frac_effective=frac(alg_bytes_per_group(n), ms), input_sets=S,
+                                note="the headline rounds dealt to three streams (independent batches): host-clock "
+                                     "time per round over 240 launches; launches overlap, so this is not a launch duration")
+    del sets
+    torch.cuda.empty_cache()
     # no arena on the device: the host keeps, per group, the index of the first entry of the
     # leader's term (rq_round_desc.log_term_start); logs of Raft's own shape (terms above the
     # leader's lowered to it)

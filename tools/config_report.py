@@ -80,19 +80,28 @@ out.append(rate("C2 10k x 3 commit only (latency-bound)", b.G, 4 * 3 + 20, sec,
 # C3 and its split kernels: 1M x 5
 G, n, S = 1 << 20, 5, 12
 hosts = [synth.gen_fused(G, n, seed=77 + s, ld=G + 256) for s in range(S)]
-for arena, bits in (("int32 log-term arena", None), ("8-bit log-term arena entries", 0)):
-    sets = [DeviceBatch(b, dev, log_term_bits=bits) for b in hosts]
+for arena, bits, tiled in (("int32 log-term arena, planes", None, False), ("8-bit log-term arena entries, planes", 0, False),
+                           ("8-bit log-term arena entries, 64-group tiles", 0, True)):
+    sets = [DeviceBatch(b, dev, log_term_bits=bits, tiled=tiled) for b in hosts]
     for s_ in sets:                       # plans built, buffers touched
         eng.fused_round(s_); eng.commit_advance(s_); eng.vote_tally(s_)
     sec = timed(lambda i: eng.fused_round(sets[i % S]), 300, 30)
     out.append(rate("C3 1M x 5 fused round, " + arena, G, 137, sec))
     sec = timed(lambda i: eng.commit_advance(sets[i % S]), 300, 30)
     out.append(rate("1M x 5 commit advance only, " + arena, G, 40, sec))
-    if bits is None:
+    if bits is None or tiled:
         sec = timed(lambda i: eng.vote_tally(sets[i % S]), 300, 30)
-        out.append(rate("1M x 5 vote tally only", G, 97, sec))
+        out.append(rate("1M x 5 vote tally only, " + ("64-group tiles" if tiled else "planes"), G, 97, sec))
     del sets
     torch.cuda.empty_cache()
+# no arena on the device: the index where the leader's term starts (logs of Raft's own shape)
+sets = [DeviceBatch(b, dev, tiled=True, term_start=synth.term_start_monotone(b)) for b in hosts]
+for s_ in sets:
+    eng.fused_round(s_)
+sec = timed(lambda i: eng.fused_round(sets[i % S]), 300, 30)
+out.append(rate("C3 1M x 5 fused round, log_term_start instead of the arena, 64-group tiles", G, 133, sec))
+del sets
+torch.cuda.empty_cache()
 del hosts
 
 # host-buffer entry point (PCIe and pageable staging inclusive) on one set
@@ -117,8 +126,9 @@ torch.cuda.empty_cache()
 # C4 at one GPU: 8M x 5
 G8 = 8 << 20
 hosts = [synth.gen_fused(G8, n, seed=300 + s, ld=G8 + 256) for s in range(2)]
-for arena, bits in (("int32 log-term arena", None), ("8-bit log-term arena entries", 0)):
-    sets = [DeviceBatch(b, dev, log_term_bits=bits) for b in hosts]
+for arena, bits, tiled in (("int32 log-term arena, planes", None, False), ("8-bit log-term arena entries, planes", 0, False),
+                           ("8-bit log-term arena entries, 64-group tiles", 0, True)):
+    sets = [DeviceBatch(b, dev, log_term_bits=bits, tiled=tiled) for b in hosts]
     sec = timed(lambda i: eng.fused_round(sets[i % 2]), 40, 5)
     out.append(rate("C4 8M x 5 fused round on ONE GPU (2 sets, 2.8 GB), " + arena, G8, 137, sec))
     del sets
