@@ -315,8 +315,8 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  *               output tile instead of 26 planes 4 MiB apart: 5 % faster at
  *               1M x 5 (one mixed tile for reads and writes gains nothing).  The
  *               log arena, elected_bits, changed_bits, the commit summary and an
- *               explicit summary_base stay plain arrays.  rq_groups_scatter_dev /
- *               _gather_dev work on planes only.
+ *               explicit summary_base stay plain arrays (rq_groups_scatter_dev /
+ *               _gather_dev address either layout).
  *   variant     kernel build: 0 = library default; RQ_VARIANT_PLAIN = default
  *               cache policy instead of non-temporal streaming; bits 8-11 =
  *               threads per block / 64 (1..4).  Never changes results.

@@ -936,7 +936,6 @@ int rq_groups_scatter_dev(rq_engine *e, void *stream, const rq_round_desc *d, ui
                           const void *row_log_terms, uint8_t *row_status) {
     rq_plan p;
     RQ_TRY(plan_from_desc(e, d, p));
-    if (d->tile_bytes) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
     hipError_t err = p.wide
         ? rq_launch_groups_scatter(p.args64, p.n, count, gids, (const int64_t *)rows, row_log_off,
@@ -952,7 +951,6 @@ int rq_groups_gather_dev(rq_engine *e, void *stream, const rq_round_desc *d, uin
                          const uint32_t *gids, void *rows_out, uint64_t *flags_out) {
     rq_plan p;
     RQ_TRY(plan_from_desc(e, d, p));
-    if (d->tile_bytes) return RQ_E_ARG;
     RQ_HIP(e, hipSetDevice(e->device));
     hipError_t err = p.wide
         ? rq_launch_groups_gather(p.args64, p.n, count, gids, (int64_t *)rows_out, flags_out, (hipStream_t)stream)

@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64) void rq_groups_scatter_kernel(rq_round_args_t<T
     if (r >= count) return;
     const uint32_t g = gids[r];
     const T *row = rows + (size_t)r * scatter_row_words(n);
+    const group_addr ga = addr_of(a, g < a.G ? g : 0u);       // planes or 64-group tiles
     uint32_t bad = 0;
     if (g >= a.G) {
         bad = kRowBadGroup;
@@ -61,13 +62,13 @@ __global__ __launch_bounds__(64) void rq_groups_scatter_kernel(rq_round_args_t<T
         if (a.log_len) {                  // the row names the slice
             room = span_ok((uint32_t)row[4 * n + 6], len, a.log_terms);
         } else {                          // tight CSR: the log keeps its length
-            const uint32_t beg = a.log_off[g], end = a.log_off[g + 1];
+            const uint32_t beg = *at(a.log_off, ga), end = *at(a.log_off, addr_of(a, g + 1));
             room = slice_ok(beg, end, a.log_terms) && len == end - beg;
         }
         if (!room) {
             bad = kRowNoRoom;
         } else {
-            const T base = a.log_term_base ? a.log_term_base[g] : (T)0;
+            const T base = a.log_term_base ? *at(a.log_term_base, ga) : (T)0;
             bool fits = true;
             for (uint32_t i = lane; i < len; i += 64)
                 fits = fits && term_fits<T>(a.log_term_bits, (T)((U)row_terms[row_off[r] + i] - (U)base));
@@ -76,39 +77,38 @@ __global__ __launch_bounds__(64) void rq_groups_scatter_kernel(rq_round_args_t<T
     }
     if (row_status && lane == 0) row_status[r] = (uint8_t)bad;
     if (bad) return;
-    const size_t ld = a.ld;
     T *planes[4] = {const_cast<T *>(a.match), const_cast<T *>(a.voter_term), const_cast<T *>(a.voted_for),
                     const_cast<T *>(a.last_log_term)};
     for (uint32_t i = lane; i < 4 * n; i += 64) {
         T *pl = planes[i / n];
-        if (pl) pl[(size_t)(i % n) * ld + g] = row[i];
+        if (pl) *at(pl, ga, i % n) = row[i];
     }
     if (lane == 0) {
         const T *tail = row + 4 * n;
-        if (a.commit) const_cast<T *>(a.commit)[g] = tail[0];
-        if (a.leader_term) const_cast<T *>(a.leader_term)[g] = tail[1];
-        if (a.cand_term) const_cast<T *>(a.cand_term)[g] = tail[2];
-        if (a.cand_id) const_cast<T *>(a.cand_id)[g] = tail[3];
-        if (a.log_base) const_cast<T *>(a.log_base)[g] = tail[4];
+        if (a.commit) *at(const_cast<T *>(a.commit), ga) = tail[0];
+        if (a.leader_term) *at(const_cast<T *>(a.leader_term), ga) = tail[1];
+        if (a.cand_term) *at(const_cast<T *>(a.cand_term), ga) = tail[2];
+        if (a.cand_id) *at(const_cast<T *>(a.cand_id), ga) = tail[3];
+        if (a.log_base) *at(const_cast<T *>(a.log_base), ga) = tail[4];
         if (a.old_mask) {
-            const_cast<uint16_t *>(a.old_mask)[g] = (uint16_t)((uint64_t)tail[5] & 0xFFFFu);
-            const_cast<uint16_t *>(a.new_mask)[g] = (uint16_t)(((uint64_t)tail[5] >> 16) & 0xFFFFu);
+            *at(const_cast<uint16_t *>(a.old_mask), ga) = (uint16_t)((uint64_t)tail[5] & 0xFFFFu);
+            *at(const_cast<uint16_t *>(a.new_mask), ga) = (uint16_t)(((uint64_t)tail[5] >> 16) & 0xFFFFu);
         }
     }
     if (a.log_term_start) {
         if (lane == 0) {
-            const_cast<T *>(a.log_term_start)[g] = row[4 * n + 6];
-            if (a.log_len) const_cast<uint32_t *>(a.log_len)[g] = row_off[r + 1] - row_off[r];
+            *at(const_cast<T *>(a.log_term_start), ga) = row[4 * n + 6];
+            if (a.log_len) *at(const_cast<uint32_t *>(a.log_len), ga) = row_off[r + 1] - row_off[r];
         }
     } else if (a.log_off) {
         const uint32_t len = row_off[r + 1] - row_off[r];
-        const uint32_t beg = a.log_len ? (uint32_t)row[4 * n + 6] : a.log_off[g];
-        if (a.log_len && lane == 0) const_cast<uint32_t *>(a.log_off)[g] = beg;
-        const T base = a.log_term_base ? a.log_term_base[g] : (T)0;
+        const uint32_t beg = a.log_len ? (uint32_t)row[4 * n + 6] : *at(a.log_off, ga);
+        if (a.log_len && lane == 0) *at(const_cast<uint32_t *>(a.log_off), ga) = beg;
+        const T base = a.log_term_base ? *at(a.log_term_base, ga) : (T)0;
         for (uint32_t i = lane; i < len; i += 64)
             store_term<T>(const_cast<void *>(a.log_term), a.log_term_bits, (size_t)beg + i,
                           (T)((U)row_terms[row_off[r] + i] - (U)base));
-        if (a.log_len && lane == 0) const_cast<uint32_t *>(a.log_len)[g] = len;
+        if (a.log_len && lane == 0) *at(const_cast<uint32_t *>(a.log_len), ga) = len;
     }
 }
 
@@ -128,17 +128,23 @@ __global__ __launch_bounds__(256) void rq_groups_gather_kernel(rq_round_args_t<T
         if (w == 0) flags_out[r] = ~0ull;
         return;
     }
+    // the outputs' own tile block, unless an output is its input updated in place
+    const group_addr ga = addr_of(a, g);
+    group_addr go = ga;
+    if (a.tile_bytes) go.tile_off = (size_t)(g >> 6) * a.out_tile_bytes;
+    const group_addr gco = (const void *)a.commit_out == (const void *)a.commit ? ga : go;
+    const group_addr gvo = (const void *)a.voter_term_out == (const void *)a.voter_term ? ga : go;
     T v = 0;
-    if (w == 0) v = a.commit_out ? a.commit_out[g] : (T)0;
-    else if (w == 1) v = a.max_term ? a.max_term[g] : (T)0;
-    else v = a.voter_term_out ? a.voter_term_out[(size_t)(w - 2) * a.ld + g] : (T)0;
+    if (w == 0) v = a.commit_out ? *at(a.commit_out, gco) : (T)0;
+    else if (w == 1) v = a.max_term ? *at(a.max_term, go) : (T)0;
+    else v = a.voter_term_out ? *at(a.voter_term_out, gvo, w - 2) : (T)0;
     rows_out[i] = v;
     if (w == 0) {
         uint64_t f = 0;
-        if (a.grant_mask) f |= (uint64_t)a.grant_mask[g];
-        if (a.stepdown_mask) f |= (uint64_t)a.stepdown_mask[g] << 16;
-        if (a.elected) f |= (uint64_t)a.elected[g] << 32;
-        if (a.status_out) f |= (uint64_t)a.status_out[g] << 40;
+        if (a.grant_mask) f |= (uint64_t)*at(a.grant_mask, go);
+        if (a.stepdown_mask) f |= (uint64_t)*at(a.stepdown_mask, go) << 16;
+        if (a.elected) f |= (uint64_t)*at(a.elected, go) << 32;
+        if (a.status_out) f |= (uint64_t)*at(a.status_out, go) << 40;
         flags_out[r] = f;
     }
 }
@@ -148,7 +154,8 @@ hipError_t launch_groups_scatter_impl(const rq_round_args_t<T> &a, uint32_t n, u
                                       const T *rows, const uint32_t *row_off, const T *row_terms,
                                       uint8_t *row_status, hipStream_t stream) {
     if (count == 0) return hipSuccess;
-    if (n < 1 || n > 16 || !gids || !rows || (a.log_off && (!row_off || !row_terms))) return hipErrorInvalidValue;
+    if (n < 1 || n > 16 || !gids || !rows) return hipErrorInvalidValue;
+    if (a.log_term_start ? !row_off : (a.log_off && (!row_off || !row_terms))) return hipErrorInvalidValue;
     hipLaunchKernelGGL((rq_groups_scatter_kernel<T>), dim3(count), dim3(64), 0, stream, a, n, count, gids, rows,
                        row_off, row_terms, row_status);
     return hipGetLastError();

@@ -235,6 +235,8 @@ class DeviceBatch:
             if a.size == 0:
                 a = np.zeros(1, a.dtype)
             host[k] = np.ascontiguousarray(a)
+        if "log_len" in batch and not term_start:   # logs with room behind them: length per group, offsets unordered
+            host["log_len"] = np.ascontiguousarray(np.asarray(batch["log_len"]).astype(np.uint32).view(np.int32))
         if "log_base" in batch:                 # windowed log arena
             host["log_base"] = np.ascontiguousarray(batch["log_base"], dtype=vdt)
         if self.joint:

@@ -1189,12 +1189,13 @@ def test_summary_consumer_applies_advances_on_the_device(dev):
         ex.close()
 
 
+@pytest.mark.parametrize("tiled", [False, True])
 @pytest.mark.parametrize("wide", [False, True])
-def test_groups_scatter_gather_and_changed_bits(dev, wide):
+def test_groups_scatter_gather_and_changed_bits(dev, wide, tiled):
     """A resident image with room behind every log: the round writes the changed-bit
     summary; rq_groups_scatter_dev replaces some groups (their logs moved to free arena
     space), the next round must equal the oracle on the edited batch; rq_groups_gather_dev
-    packs chosen groups' outputs; refused rows leave their group alone."""
+    packs chosen groups' outputs; refused rows leave their group alone.  In planes and in 64-group tiles."""
     import ctypes as C
     import torch
     from raft_amd.device import DeviceBatch
@@ -1212,10 +1213,10 @@ def test_groups_scatter_gather_and_changed_bits(dev, wide):
     img = synth.Batch(b)
     img["log_off"], img["log_term"] = off.astype(np.uint32), arena
     batch = synth.widen(img)[0] if wide else img
+    batch["log_len"] = lens.astype(np.uint32)
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
     for bits in ((None, 8) if not wide else (None,)):
-        db = DeviceBatch(batch, in_place=True, log_term_bits=bits)
-        db.t["log_len"] = up(lens.astype(np.int32))
+        db = DeviceBatch(batch, in_place=True, log_term_bits=bits, tiled=tiled)
         db.o["changed_bits"] = torch.zeros((G + 63) // 64, dtype=torch.int64, device="cuda:0")
         exp = o.fused_round(*b.fused_args(), G=G)
         dev.fused_round(db)
@@ -1342,10 +1343,8 @@ def test_tiled_layout(dev, kind):
                 dc = DeviceBatch(batch, tiled=True)
                 dev.commit_advance(dc); dev.vote_tally(dc)
                 _check_dev(dc.results(), exp, G)
-    # the single-group calls work on planes only
     import ctypes as C
     d = dev.describe(db)
-    assert dev._l.rq_groups_gather_dev(dev._h, None, C.byref(d), 1, None, None, None) == -1
     d.tile_bytes = 100
     assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == -1        # not a multiple of 8
     d.tile_bytes, d.out_tile_bytes = db.tile_bytes, 0
