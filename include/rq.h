@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RQ_VERSION 0x000202 /* 0.2.2: rq_round_desc gained start_signal and log_term_start, rq_append_desc the tile strides */
+#define RQ_VERSION 0x000203 /* 0.2.3: rq_append_desc gained the follower commit clamp (leader_commit, last_new_index, follower_commit_io) */
 
 /* return codes */
 #define RQ_OK            0
@@ -414,7 +414,19 @@ int rq_plan_destroy(rq_plan *p);
  *                   unless it is follower_term itself) with out_tile_bytes; ld is
  *                   ignored; flog_off is per slot, element (p, g) the start of follower
  *                   (p, g)'s log and element (p, g + 1) its end, g = 0 .. G (tile G / 64
- *                   must exist). */
+ *                   must exist);
+ *   leader_commit [G] / last_new_index [n][ld] / follower_commit_io [n][ld]
+ *                   all NULL, or all given: the same launch then also applies the
+ *                   follower's commit rule of raft.go:172-176 to every slot whose RPC
+ *                   succeeds, in place: commitIndex below leaderCommit becomes
+ *                   min(leaderCommit, last_new_index), last_new_index being
+ *                   lastEntry(newEntries).Index as the host read it (it may lower
+ *                   commitIndex, as the reference does).  A succeeding slot with
+ *                   leaderCommit above its commitIndex and n_new == 0 (n_new given) is
+ *                   the reference's lastEntry(newEntries) panic (:175, :235):
+ *                   RQ_ST_EMPTY_LOG, commitIndex unchanged.  Other slots keep their
+ *                   commitIndex.  The steps between (:158-170, the log mutation) stay
+ *                   with the host, which also vouches that they do not panic. */
 typedef struct rq_append_desc {
     uint32_t struct_size;       /* sizeof(rq_append_desc) */
     uint32_t layout;            /* RQ_LAYOUT_I32 or RQ_LAYOUT_I64 */
@@ -430,6 +442,8 @@ typedef struct rq_append_desc {
     void *match_index_io, *next_index_io;
     uint8_t *status_out;
     uint64_t tile_bytes, out_tile_bytes;
+    const void *leader_commit, *last_new_index;
+    void *follower_commit_io;
 } rq_append_desc;
 int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d);
 

@@ -593,6 +593,39 @@ int NAME(uint32_t G, uint32_t n, uint32_t ld, \
 ORC_DEFINE_APPEND_CHECK(orc_append_check, int32_t)
 ORC_DEFINE_APPEND_CHECK(orc_append_check64, int64_t)
 
+/* raft.go:172-176 for the slots of an AppendEntries batch whose RPC succeeded
+ * (success_mask as orc_append_check wrote it): a commitIndex below leaderCommit
+ * becomes minInt(leaderCommit, lastEntry(newEntries).Index) (:175, :226-231).
+ * last_new_index[s] is that entry's Index; n_new[s] == 0 (n_new given) means
+ * newEntries is empty, so lastEntry indexes ents[-1] (:235): an index panic in
+ * Go, reported as ORC_ST_EMPTY_LOG with commitIndex as it was.  Slots without
+ * success returned at :146 or :152 and keep their commitIndex. */
+#define ORC_DEFINE_APPEND_COMMIT(NAME, T) \
+int NAME(uint32_t G, uint32_t n, uint32_t ld, const uint16_t *success_mask, \
+         const T *leader_commit, const T *last_new_index, const T *n_new, \
+         T *follower_commit_io, uint8_t *status_io) { \
+    if (n < 1 || n > ORC_MAX_SLOTS || ld < G) return -1; \
+    for (uint32_t g = 0; g < G; g++) { \
+        for (uint32_t p = 0; p < n; p++) { \
+            if (!(success_mask[g] >> p & 1)) continue; \
+            size_t s = (size_t)p * ld + g; \
+            if ((int64_t)leader_commit[g] > (int64_t)follower_commit_io[s]) { /* :174 */ \
+                rf_entry e = { "", (int64_t)last_new_index[s], 0 }, last; \
+                int64_t count = (n_new && n_new[s] == 0) ? 0 : 1; \
+                if (rf_last_entry(&e, count, &last) != RF_OK) { /* :175 -> :235 */ \
+                    if (status_io) status_io[g] |= ORC_ST_EMPTY_LOG; \
+                    continue; \
+                } \
+                follower_commit_io[s] = (T)rf_min_int((int64_t)leader_commit[g], last.index); \
+            } \
+        } \
+    } \
+    return 0; \
+}
+
+ORC_DEFINE_APPEND_COMMIT(orc_append_commit, int32_t)
+ORC_DEFINE_APPEND_COMMIT(orc_append_commit64, int64_t)
+
 /* ------------------------------------------------------------------------ */
 /* CPU baseline: heap-allocated reference-shaped clusters                    */
 /* ------------------------------------------------------------------------ */

@@ -148,6 +148,14 @@ int orc_append_check(uint32_t G, uint32_t n, uint32_t ld,
                      uint16_t *stepdown_mask, int32_t *match_index_io,
                      int32_t *next_index_io, uint8_t *status_out); /* :142-153 */
 
+/* :172-176 for the succeeding slots of an AppendEntries batch (in place) */
+int orc_append_commit(uint32_t G, uint32_t n, uint32_t ld, const uint16_t *success_mask,
+                      const int32_t *leader_commit, const int32_t *last_new_index,
+                      const int32_t *n_new, int32_t *follower_commit_io, uint8_t *status_io);
+int orc_append_commit64(uint32_t G, uint32_t n, uint32_t ld, const uint16_t *success_mask,
+                        const int64_t *leader_commit, const int64_t *last_new_index,
+                        const int64_t *n_new, int64_t *follower_commit_io, uint8_t *status_io);
+
 /* wide-layout forms of the two functions above */
 int orc_follower_clamp64(uint64_t count, const int64_t *leader_commit,
                          const int64_t *commit, const int64_t *last_new_index,

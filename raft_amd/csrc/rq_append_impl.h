@@ -20,6 +20,10 @@ namespace {
 // nextIndex/matchIndex, raft.go:60-68): success -> match = prev + n_new,
 // next = match + 1; rejected at the log check -> next = max(next - 1, 1);
 // rejected for a stale term -> unchanged.
+// Follower commit (optional, raft.go:172-176): a slot whose RPC succeeds and whose
+// commitIndex is below leaderCommit takes min(leaderCommit, index of the last new
+// entry); with no new entries (n_new == 0) the reference's lastEntry(newEntries)
+// panics (:175, :235): status bit, commitIndex unchanged.
 // ---------------------------------------------------------------------------
 // NMAX = compile-time slot bound (the loop over slots is fully unrolled so that
 // every plane load of a group is in flight before the first gather).
@@ -31,7 +35,9 @@ __device__ __forceinline__ size_t append_index(uint64_t tile_bytes, size_t ld, u
     else return (size_t)p * ld + g;
 }
 
-template <int NMAX, bool TILED, typename T>
+// CLAMP: the follower commit rule is part of the launch (a build of its own: its two extra
+// planes per slot would otherwise cost every launch 12 registers per slot).
+template <int NMAX, bool TILED, bool CLAMP, typename T>
 __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_t<T> a) {
     typedef typename std::make_unsigned<T>::type U;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -44,11 +50,13 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     uint32_t act = a.active_mask ? (uint32_t)a.active_mask[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)] : 0xFFFFu;
     act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
     const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
-    T ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX], fb[NMAX];
+    constexpr bool clamp = CLAMP;
+    const T lc = clamp ? __builtin_nontemporal_load(a.leader_commit + gT) : (T)0;
+    T ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX], fb[NMAX], fc[NMAX], li[NMAX];
     uint32_t o0[NMAX], o1[NMAX];
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
-        ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = fb[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
+        ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = fb[p] = fc[p] = li[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
         if ((act >> p) & 1u) {
             const size_t s = append_index<TILED, T>(a.tile_bytes, ld, g, p);
             const size_t so = append_index<TILED, uint32_t>(a.tile_bytes, ld, g, p);
@@ -62,6 +70,10 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
             if (a.n_new) nn[p] = __builtin_nontemporal_load(a.n_new + s);
             if (a.match_index_io) mi[p] = __builtin_nontemporal_load(a.match_index_io + s);
             if (a.next_index_io) ni[p] = __builtin_nontemporal_load(a.next_index_io + s);
+            if constexpr (clamp) {
+                fc[p] = __builtin_nontemporal_load(a.follower_commit_io + s);
+                li[p] = __builtin_nontemporal_load(a.last_new_index + s);
+            }
         }
     }
     uint32_t reach = 0, inb = 0, bad = 0;
@@ -99,6 +111,14 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
             else if (r) { n2 = n2 > 1 ? n2 - 1 : 1; }
             if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
             if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
+        }
+        if constexpr (clamp) {
+            T c2 = fc[p];
+            if (success && lc > fc[p]) {                                  // raft.go:174
+                if (a.n_new && nn[p] == 0) st |= kStEmptyLog;             // lastEntry of no entries, :175 / :235
+                else c2 = tmin(lc, li[p]);
+            }
+            __builtin_nontemporal_store(c2, a.follower_commit_io + s);
         }
     }
     const size_t g16 = append_index<TILED, uint16_t>(out_tile, ld, g, 0);
@@ -141,20 +161,25 @@ hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, hipStream_t st
     if (tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
     const uint32_t block = 128;
     const dim3 grid((a.G + block - 1) / block), blk(block);
-#define RQ_APPEND_CASE(N)                                                                                   \
-    case N:                                                                                                 \
-        if (a.tile_bytes) hipLaunchKernelGGL((rq_append_check_kernel<N, true, T>), grid, blk, 0, stream, a); \
-        else hipLaunchKernelGGL((rq_append_check_kernel<N, false, T>), grid, blk, 0, stream, a);            \
+    const int clamp_ptrs = (a.leader_commit != nullptr) + (a.last_new_index != nullptr) + (a.follower_commit_io != nullptr);
+    if (clamp_ptrs != 0 && clamp_ptrs != 3) return hipErrorInvalidValue;
+    const bool clamp = clamp_ptrs == 3, tiled = a.tile_bytes != 0;
+#define RQ_APPEND_LAUNCH(N, TILED, CLAMP) \
+    hipLaunchKernelGGL((rq_append_check_kernel<N, TILED, CLAMP, T>), grid, blk, 0, stream, a)
+#define RQ_APPEND_CASE(N)                                             \
+    case N:                                                           \
+        if (tiled && clamp) RQ_APPEND_LAUNCH(N, true, true);          \
+        else if (tiled) RQ_APPEND_LAUNCH(N, true, false);             \
+        else if (clamp) RQ_APPEND_LAUNCH(N, false, true);             \
+        else RQ_APPEND_LAUNCH(N, false, false);                       \
         break;
-    switch (a.n) {
+    switch (a.n <= 9 ? a.n : 16u) {
     RQ_APPEND_CASE(1) RQ_APPEND_CASE(2) RQ_APPEND_CASE(3) RQ_APPEND_CASE(4) RQ_APPEND_CASE(5)
-    RQ_APPEND_CASE(6) RQ_APPEND_CASE(7) RQ_APPEND_CASE(8) RQ_APPEND_CASE(9)
-    default:
-        if (a.tile_bytes) hipLaunchKernelGGL((rq_append_check_kernel<16, true, T>), grid, blk, 0, stream, a);
-        else hipLaunchKernelGGL((rq_append_check_kernel<16, false, T>), grid, blk, 0, stream, a);
-        break;
+    RQ_APPEND_CASE(6) RQ_APPEND_CASE(7) RQ_APPEND_CASE(8) RQ_APPEND_CASE(9) RQ_APPEND_CASE(16)
+    default: break;
     }
 #undef RQ_APPEND_CASE
+#undef RQ_APPEND_LAUNCH
     return hipGetLastError();
 }
 

@@ -392,6 +392,8 @@ int append_args_ok(const rq_append_args_t<T> &a) {
     if (!a.follower_term || !a.leader_term || !a.prev_log_index || !a.prev_log_term ||
         !a.flog_off || !a.flog_term || !a.follower_term_out || !a.success_mask || !a.stepdown_mask)
         return RQ_E_ARG;
+    const int clamp_ptrs = (a.leader_commit != nullptr) + (a.last_new_index != nullptr) + (a.follower_commit_io != nullptr);
+    if (clamp_ptrs != 0 && clamp_ptrs != 3) return RQ_E_ARG;
     return RQ_OK;
 }
 
@@ -479,6 +481,8 @@ int append_check_dev(rq_engine *e, void *stream, const rq_append_desc &d) {
     a.stepdown_mask = d.stepdown_mask; a.match_index_io = (T *)d.match_index_io;
     a.next_index_io = (T *)d.next_index_io; a.status_out = d.status_out;
     a.tile_bytes = d.tile_bytes; a.out_tile_bytes = d.out_tile_bytes;
+    a.leader_commit = (const T *)d.leader_commit; a.last_new_index = (const T *)d.last_new_index;
+    a.follower_commit_io = (T *)d.follower_commit_io;
     if (a.flog_term_bits > 8 * sizeof(T) || d.flog_terms > 0xFFFFFFFFull) return RQ_E_ARG;
     if (!a.flog_term && d.flog_terms == 0) a.flog_term = a.flog_off;   // empty arena: never dereferenced
     RQ_TRY(append_args_ok(a));

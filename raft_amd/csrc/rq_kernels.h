@@ -114,6 +114,11 @@ struct rq_append_args_t {
     T *match_index_io;              // [n][ld], may be null
     T *next_index_io;               // [n][ld], may be null
     uint8_t  *status_out;           // [G], may be null
+    // The follower's commit clamp (raft.go:172-176) for the slots whose RPC succeeds; all three
+    // null, or all three given (updated in place like match_index_io):
+    const T *leader_commit;         // [G]
+    const T *last_new_index;        // [n][ld]: lastEntry(newEntries).Index
+    T *follower_commit_io;          // [n][ld]
     // 0 = slot-major planes and a CSR over slot ids s = p * ld + g.  Else the 64-group tiles of
     // the round kernels (rq_round_args_t): tile_bytes is the stride of the block that holds the
     // inputs and the arrays updated in place, out_tile_bytes that of the pure outputs

@@ -96,7 +96,10 @@ class TiledAppendBatch:
         off = np.asarray(b["flog_off"]).astype(np.int64)
         off_ps = np.stack([off[p * ld: p * ld + G + 1] for p in range(n)]).astype(np.uint32).view(np.int32)
         ins = [(k, n, np.asarray(b[k])[:, :G]) for k in ("follower_term", "prev_log_index", "prev_log_term", "n_new",
-                                                      "match_index", "next_index") if k in b]
+                                                      "match_index", "next_index", "last_new_index",
+                                                      "follower_commit") if k in b]
+        if "leader_commit" in b:
+            ins.append(("leader_commit", 1, np.asarray(b["leader_commit"])[None, :G]))
         if "flog_base" in b:
             ins.append(("flog_base", n, np.asarray(b["flog_base"])[:, :G]))
         ins.append(("flog_off", n, off_ps))
@@ -521,7 +524,8 @@ class DeviceEngine:
         """Enqueue the AppendEntries consistency batch on device tensors
         (rq_append_check_dev; int32 or int64 planes).  t: dict of tensors with the C-ABI
         names; active_mask, n_new, match_index, next_index, status, flog_base and
-        flog_term_base may be absent.  follower_term_out may be the follower_term tensor
+        flog_term_base may be absent; leader_commit + last_new_index + follower_commit
+        (all three or none) add the follower's commit clamp of raft.go:172-176.  follower_term_out may be the follower_term tensor
         itself (in-place terms); match_index / next_index are updated in place.
         flog_term_bits: entry width of the flog_term tensor (0 = the planes' element)."""
         wide = t["follower_term"].dtype == torch.int64 if wide is None else wide
@@ -542,6 +546,8 @@ class DeviceEngine:
         d.success_mask, d.stepdown_mask = p("success_mask"), p("stepdown_mask")
         d.match_index_io, d.next_index_io = p("match_index"), p("next_index")
         d.status_out = p("status")
+        d.leader_commit, d.last_new_index = p("leader_commit"), p("last_new_index")
+        d.follower_commit_io = p("follower_commit")
         rc = self._l.rq_append_check_dev(self._h, self._stream(), C.byref(d))
         if rc != 0:
             self._check(rc, "rq_append_check_dev")

@@ -343,6 +343,24 @@ def gen_append(G, n, seed=DEFAULT_SEED, ld=None, max_len=12, adversarial=False):
                  active_mask=act.astype(np.uint16))
 
 
+def with_follower_commit(b, seed=DEFAULT_SEED):
+    """A copy of a gen_append batch with the inputs of the follower's commit rule
+    (raft.go:172-176): the RPC's leaderCommit per group, every follower's commitIndex
+    and the Index of the last new entry -- prevLogIndex + n_new for most slots, an
+    arbitrary small value for a fifth of them (the reference takes whatever Index the
+    entry carries, also one below commitIndex)."""
+    G, n, ld = int(b["G"]), int(b["n"]), int(b["ld"])
+    sidx = np.arange(n * ld, dtype=np.int64)
+    dt = b["follower_term"].dtype
+    w = Batch(b)
+    w["leader_commit"] = _below(seed, F_COMMIT, 3 * n * ld + np.arange(G), 16).astype(dt)
+    w["follower_commit"] = _below(seed, F_MATCH, 5 * n * ld + sidx, 12).astype(dt).reshape(n, ld)
+    usual = b["prev_log_index"].astype(np.int64).reshape(-1) + b["n_new"].astype(np.int64).reshape(-1)
+    odd = _below(seed, F_AUX, 7 * n * ld + sidx, 10)
+    w["last_new_index"] = np.where(_unit(seed, F_AUX2, 9 * n * ld + sidx) < 0.2, odd, usual).astype(dt).reshape(n, ld)
+    return w
+
+
 def window_logs(b, keep_committed=0):
     """A copy of batch b whose log arena holds, for every group, only the entries
     above commitIndex - keep_committed (the uncommitted suffix plus a few entries

@@ -75,6 +75,8 @@ def lib():
         l.orc_append_check.argtypes = [u32, u32, u32, u16p, i32p, i32p, i32p, i32p, i32p, u32p, i32p,
                                        i32p, u16p, u16p, i32p, i32p, u8p]
         l.orc_follower_clamp64.argtypes = [C.c_uint64] + [C.c_void_p] * 4
+        l.orc_append_commit.argtypes = [u32, u32, u32] + [C.c_void_p] * 6
+        l.orc_append_commit64.argtypes = [u32, u32, u32] + [C.c_void_p] * 6
         l.orc_append_check64.argtypes = [u32, u32, u32] + [C.c_void_p] * 14
         l.orc_round64.argtypes = [C.c_int, u32, u32, u32] + [C.c_void_p] * 20
         l.orc_bench_build.argtypes = [u32, u32, u32, i32p, i32p, i32p, u32p, i32p, i32p, i32p, i32p,
@@ -219,6 +221,20 @@ def append_check(follower_term, leader_term, prev_log_index, prev_log_term, flog
                                 _p(out.status, u8p))
     assert rc == 0, rc
     return out
+
+
+def append_commit(res, leader_commit, last_new_index, follower_commit, n_new=None, G=None):
+    """raft.go:172-176 for the succeeding slots of an append_check result `res`: returns
+    the followers' commitIndex planes afterwards and ORs the panic bit into res.status.
+    Element type from follower_commit (int32 or int64)."""
+    dt = np.asarray(follower_commit).dtype
+    fc = _c(follower_commit, dt).copy(); n, ld = fc.shape; G = ld if G is None else G
+    lc, li = _c(leader_commit, dt), _c(last_new_index, dt)
+    nn = None if n_new is None else _c(n_new, dt)
+    vp = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+    fn = lib().orc_append_commit64 if dt == np.int64 else lib().orc_append_commit
+    assert fn(G, n, ld, vp(res.success_mask), vp(lc), vp(li), vp(nn), vp(fc), vp(res.status)) == 0
+    return fc
 
 
 def follower_clamp64(leader_commit, commit, last_new_index):

@@ -1545,3 +1545,94 @@ def test_replicate_then_commit_on_one_tiled_image(dev):
     assert np.array_equal(tb.fetch("match_index"), exp_a["match_index"][:, :G])
     assert np.array_equal(tb.fetch("commit_out"), exp_c) and np.array_equal(tb.fetch("round_status"), exp_st)
     assert (exp_c != c.commit).mean() > 0.01 and (exp_st != 0).any()
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("tiled", [False, True])
+def test_append_check_with_the_follower_commit_rule(dev, wide, tiled):
+    """rq_append_desc.leader_commit / last_new_index / follower_commit_io: the launch that
+    checks the RPCs also applies raft.go:172-176 to the slots that succeed -- commitIndex
+    below leaderCommit becomes min(leaderCommit, Index of the last new entry), which may
+    lower it; no new entries there is the reference's lastEntry panic (status bit,
+    commitIndex kept); slots that fail or receive no RPC keep theirs.  Against the oracle,
+    in planes and on tiles, int32 and int64."""
+    import ctypes as C
+    import torch
+    from raft_amd import _lib
+    from raft_amd.device import TiledAppendBatch
+    oc = o.append_check64 if wide else o.append_check
+    dt = np.int64 if wide else np.int32
+
+    def widen(b):
+        if not wide:
+            return b
+        w = synth.Batch(b)
+        for k in ("follower_term", "leader_term", "prev_log_term", "flog_term"):
+            w[k] = b[k].astype(np.int64) + (1 << 40)
+        for k in ("prev_log_index", "n_new", "match_index", "next_index"):
+            w[k] = b[k].astype(np.int64)
+        return w
+
+    def run(b, G, n, ld):
+        """device planes / tiles -> (follower_commit [n][G], status [G], success [G])"""
+        if tiled:
+            tb = TiledAppendBatch(b, term_bits=0)
+            dev.append_check(tb.t, G, n, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=tb.wide)
+            return (tb.fetch("follower_commit").reshape(n, G), tb.fetch("status"),
+                    tb.fetch("success_mask").view(np.uint16))
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+        t = {k: up(b[k]) for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
+                                   "match_index", "next_index", "leader_commit", "last_new_index", "follower_commit")}
+        t["active_mask"] = up(b.active_mask.view(np.int16))
+        t["flog_off"] = up(b.flog_off.view(np.int32))
+        t["flog_term"] = up(b.flog_term if b.flog_term.size else np.zeros(1, dt))
+        t["follower_term_out"] = t["follower_term"]
+        t["success_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
+        t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
+        t["status"] = torch.zeros(G, dtype=torch.uint8, device="cuda:0")
+        dev.append_check(t, G, n, ld, flog_terms=int(b.flog_term.size), wide=wide)
+        torch.cuda.synchronize()
+        return (t["follower_commit"].cpu().numpy()[:, :G], t["status"].cpu().numpy(),
+                t["success_mask"].cpu().numpy().view(np.uint16))
+
+    lowered = raised = panicked = 0
+    for n in (1, 3, 5, 9):
+        for G, ld in ((1, 1), (64, 70), (4099, 4099), (30011, 30080)):
+            for adv in (False, True):
+                b = synth.with_follower_commit(widen(synth.gen_append(G, n, seed=13 * n + G, ld=ld, adversarial=adv)),
+                                               seed=n + G)
+                args, kw = _append_args(b)
+                exp = oc(*args, **kw)
+                exp_fc = o.append_commit(exp, b.leader_commit, b.last_new_index, b.follower_commit, n_new=b.n_new, G=G)
+                fc, st, ok = run(b, G, n, ld)
+                case = (n, G, adv)
+                assert np.array_equal(ok, exp["success_mask"][:G]), case
+                assert np.array_equal(fc, exp_fc[:, :G]), case
+                assert np.array_equal(st, exp["status"][:G]), case
+                lowered += int((exp_fc[:, :G] < b.follower_commit[:, :G]).sum())
+                raised += int((exp_fc[:, :G] > b.follower_commit[:, :G]).sum())
+                panicked += int(((exp["status"][:G] & 2) != 0).sum())
+    assert lowered > 100 and raised > 1000 and panicked > 100
+    # known answers (leaderCommit, commitIndex, last new Index) -> commitIndex, all four RPCs succeeding
+    kb = synth.Batch(G=4, n=1, ld=4, follower_term=np.full((1, 4), 2, dt), leader_term=np.full(4, 2, dt),
+                     prev_log_index=np.zeros((1, 4), dt), prev_log_term=np.full((1, 4), 1, dt),
+                     n_new=np.ones((1, 4), dt), match_index=np.zeros((1, 4), dt), next_index=np.ones((1, 4), dt),
+                     flog_off=np.arange(5, dtype=np.uint32), flog_term=np.ones(4, dt),
+                     active_mask=np.ones(4, np.uint16),
+                     leader_commit=np.array([5, 5, 3, 5], dt), follower_commit=np.array([[3, 3, 3, 4]], dt),
+                     last_new_index=np.array([[4, 9, 9, 2]], dt))
+    fc, st, ok = run(kb, 4, 1, 4)
+    assert ok.tolist() == [1, 1, 1, 1] and fc.tolist() == [[4, 5, 3, 2]] and not st.any()
+    kb["n_new"] = np.array([[0, 1, 0, 0]], dt)                  # heartbeats: lastEntry of no entries where lc > ci
+    fc, st, ok = run(kb, 4, 1, 4)
+    assert fc.tolist() == [[3, 5, 3, 4]] and st.tolist() == [2, 0, 0, 2]
+    # all three pointers or none
+    d = _lib.AppendDesc()
+    d.struct_size = C.sizeof(_lib.AppendDesc)
+    d.layout, d.G, d.n, d.ld = (8 if wide else 4), 4, 1, 4
+    z = torch.zeros(64, dtype=torch.int64, device="cuda:0")
+    for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "flog_off", "flog_term",
+              "follower_term_out", "success_mask", "stepdown_mask", "leader_commit"):
+        setattr(d, k, z.data_ptr())
+    d.flog_terms = 1
+    assert dev._l.rq_append_check_dev(dev._h, None, C.byref(d)) == -1

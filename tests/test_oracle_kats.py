@@ -414,3 +414,67 @@ def test_term_start_rule_equals_the_lookup_on_raft_shaped_logs():
         if "log_base" not in b0:
             s2, l2 = synth.term_start_monotone(b0)
             assert np.array_equal(s2, start) and np.array_equal(l2, ln)
+
+
+@pytest.mark.parametrize("dt", [np.int32, np.int64])
+def test_follower_commit_rule_after_a_successful_append(dt):
+    """raft.go:172-176 as orc_append_commit restates it for a batch: only slots whose RPC
+    succeeded are touched; (leaderCommit, commitIndex, last new Index) -> commitIndex as in
+    the clamp's known answers, the decrease included; no new entries where leaderCommit is
+    above commitIndex is the lastEntry panic (:175, :235): status bit, commitIndex kept."""
+    check = o.append_check64 if dt == np.int64 else o.append_check
+    G = 5
+    ft = np.array([[2, 2, 2, 2, 9]], dt)                       # the last follower is ahead of its leader: no success
+    args = (ft, np.full(G, 2, dt), np.zeros((1, G), dt), np.ones((1, G), dt),
+            np.arange(G + 1, dtype=np.uint32), np.ones(G, dt))
+    lc, ci, li = np.array([5, 5, 3, 5, 5], dt), np.array([[3, 3, 3, 4, 1]], dt), np.array([[4, 9, 9, 2, 4]], dt)
+    res = check(*args, n_new=np.ones((1, G), dt))
+    assert res.success_mask.tolist() == [1, 1, 1, 1, 0]
+    out = o.append_commit(res, lc, li, ci, n_new=np.ones((1, G), dt))
+    assert out.tolist() == [[4, 5, 3, 2, 1]] and not res.status.any()
+    res = check(*args, n_new=np.array([[0, 1, 0, 0, 0]], dt))
+    out = o.append_commit(res, lc, li, ci, n_new=np.array([[0, 1, 0, 0, 0]], dt))
+    assert out.tolist() == [[3, 5, 3, 4, 1]] and res.status.tolist() == [2, 0, 0, 2, 0]
+
+
+def test_batch_commit_rule_equals_per_node_append_entries_rpc():
+    """The batch form (orc_append_check + orc_append_commit) against the per-node restatement
+    of AppendEntriesRPC fed real entries, inside the domain where raft.go:158-167 does not
+    panic (every new entry's Index below the follower's log length; heartbeats included):
+    same success, same term, same commitIndex, and a panic exactly where the batch flags one."""
+    rng = np.random.default_rng(11)
+    G = 400
+    lens = rng.integers(1, 9, G)
+    logs = [rng.integers(1, 4, l).cumsum() // 2 + 1 for l in lens]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+    ft = rng.integers(1, 5, (1, G)).astype(np.int32)
+    lt = rng.integers(1, 5, G).astype(np.int32)
+    pi = np.array([[rng.integers(0, l) for l in lens]], np.int32)
+    pt = np.array([[logs[g][pi[0, g]] + (rng.random() < 0.25) for g in range(G)]], np.int32)
+    nn = rng.integers(0, 3, (1, G)).astype(np.int32)
+    li = np.array([[rng.integers(0, l) for l in lens]], np.int32)       # Index of the last new entry: inside the log
+    lc = rng.integers(0, 10, G).astype(np.int32)
+    ci = rng.integers(0, 8, (1, G)).astype(np.int32)
+    res = o.append_check(ft, lt, pi, pt, off, np.concatenate(logs).astype(np.int32), n_new=nn)
+    fc = o.append_commit(res, lc, li, ci, n_new=nn)
+    seen = set()
+    for g in range(G):
+        c = Cluster(1)
+        try:
+            c.seed_log(0, [int(t) for t in logs[g]])
+            nd = c.nodes[0].contents
+            nd.current_term, nd.commit_index = int(ft[0, g]), int(ci[0, g])
+            k = int(nn[0, g])
+            ents = (o.Entry * max(1, k))(*[o.Entry(b"x", int(li[0, g]), 1) for _ in range(k)])
+            tr = C.c_int64(); ok = C.c_int()
+            rc = c.l.rf_append_entries_rpc(c.nodes[0], int(lt[g]), 0, int(pi[0, g]), int(pt[0, g]), ents, k,
+                                           int(lc[g]), C.byref(tr), C.byref(ok))
+            flagged = bool(res.status[g] & o.ST_EMPTY_LOG)
+            assert (rc == o.PANIC_INDEX) == flagged, g
+            # a panic at :175 comes after every check passed: the batch reports such a slot as succeeding
+            assert bool(res.success_mask[g] & 1) == (bool(ok.value) or flagged), g
+            assert nd.current_term == res.follower_term[0, g] and nd.commit_index == fc[0, g], g
+            seen.add((bool(ok.value), flagged, int(fc[0, g]) != int(ci[0, g])))
+        finally:
+            c.close()
+    assert {(True, False, True), (True, False, False), (False, False, False), (False, True, False)} <= seen
