@@ -39,7 +39,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak
-KERNEL_SOURCES = ("raft_amd/csrc/rq_round_impl.h", "raft_amd/csrc/rq_kernels.h", "raft_amd/csrc/rq_kernels.hip")
+# the round kernels and their argument structure (rq_kernels.h also declares the other kernels' arguments)
+KERNEL_SOURCES = ("raft_amd/csrc/rq_round_impl.h", "raft_amd/csrc/rq_kernels.h:rq_round_args_t")
 
 
 def alg_bytes_per_group(n, what="fused", layout="i32"):
@@ -58,8 +59,12 @@ def kernel_source_hash():
     import re
     h = hashlib.sha1()
     for rel in KERNEL_SOURCES:
+        rel, _, struct = rel.partition(":")
         with open(os.path.join(ROOT, rel), "r") as f:
             text = f.read()
+        if struct:                                   # only this structure's definition
+            start = text.index("struct " + struct + " {")
+            text = text[start: text.index("\n};", start)]
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         text = re.sub(r"//[^\n]*", "", text)
         h.update(re.sub(r"\s+", "", text).encode())
@@ -295,6 +300,16 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     out["append_check"] = dict(kernel_ms=ms, frac=frac(abytes, ms), input_sets=A, alg_bytes_per_group=abytes,
                                note="AppendEntries consistency batch, %d follower planes, %d-bit follower-log entries"
                                     % (n - 1, asets[0]["_bits"]))
+    # the same launch also applying the follower's commit rule (raft.go:172-176) to the slots that succeed
+    for s, t in enumerate(asets):
+        cb = synth.with_follower_commit(synth.gen_append(G, n - 1, seed=900 + s), seed=s)
+        t.update({k: up(cb[k]) for k in ("leader_commit", "last_new_index", "follower_commit")})
+    ms = timed_launches(torch, device, lambda i: eng.append_check(
+        asets[i % A], G, n - 1, G, flog_term_bits=asets[i % A]["_bits"], flog_terms=asets[i % A]["_terms"]),
+        steps, warmup, A)
+    cbytes = abytes + 12 * (n - 1) + 4
+    out["append_check_commit"] = dict(kernel_ms=ms, frac=frac(cbytes, ms), input_sets=A, alg_bytes_per_group=cbytes,
+                                      note="AppendEntries batch + follower commit rule in one launch")
     del asets
     torch.cuda.empty_cache()
 
