@@ -161,7 +161,7 @@ torch.cuda.empty_cache()
 from raft_amd.device import encode_log_terms
 
 
-def append_sets(n, use_mask, term_bits, window, count=6):
+def append_sets(n, use_mask, term_bits, window, count=6, commit_rule=False):
     """Device tensors of `count` AppendEntries batches.  n = 5 with the leader's own slot
     masked out (holes in every plane line), or n = 4 follower planes and no mask."""
     out = []
@@ -179,6 +179,9 @@ def append_sets(n, use_mask, term_bits, window, count=6):
             t["active_mask"] = up(b.active_mask.view(np.int16))
         if window:
             t["flog_base"] = up(b.flog_base)
+        if commit_rule:
+            cb = synth.with_follower_commit(b, seed=s_)
+            t.update({k: up(cb[k]) for k in ("leader_commit", "last_new_index", "follower_commit")})
         t["follower_term_out"] = torch.zeros_like(t["follower_term"])
         t["success_mask"] = torch.zeros(G, dtype=torch.int16, device=dev)
         t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device=dev)
@@ -190,15 +193,18 @@ def append_sets(n, use_mask, term_bits, window, count=6):
 
 # per active follower: term, prevIdx, prevTerm, off, gathered term, n_new, match, next in; term', match', next' out
 APPEND_ALG = 44 * 4 + 4 + 2 + 2 + 2
-for label, n_planes, use_mask, term_bits, window in (
-        ("5 slot planes, leader's slot masked out, int32 follower logs", 5, True, 32, False),
-        ("5 slot planes, leader's slot masked out, 8-bit follower-log entries", 5, True, 0, False),
-        ("4 follower planes (no mask, no holes), 8-bit entries", 4, False, 0, False),
-        ("4 follower planes, 8-bit entries, logs windowed to the suffix around prevLogIndex", 4, False, 0, True)):
-    dab = append_sets(n_planes, use_mask, term_bits, window)
+for label, n_planes, use_mask, term_bits, window, commit_rule in (
+        ("5 slot planes, leader's slot masked out, int32 follower logs", 5, True, 32, False, False),
+        ("5 slot planes, leader's slot masked out, 8-bit follower-log entries", 5, True, 0, False, False),
+        ("4 follower planes (no mask, no holes), 8-bit entries", 4, False, 0, False, False),
+        ("4 follower planes, 8-bit entries, logs windowed to the suffix around prevLogIndex", 4, False, 0, True, False),
+        ("4 follower planes, 8-bit entries, + the follower commit rule (raft.go:172-176) in the same launch",
+         4, False, 0, False, True)):
+    dab = append_sets(n_planes, use_mask, term_bits, window, commit_rule=commit_rule)
     sec = timed(lambda i: eng.append_check(dab[i % len(dab)], G, n_planes, G, flog_term_bits=dab[i % len(dab)]["_bits"],
                                            flog_terms=dab[i % len(dab)]["_terms"]), 200, 20)
-    out.append(rate("AppendEntries consistency batch 1M groups x 4 followers: " + label, G, APPEND_ALG, sec,
+    out.append(rate("AppendEntries consistency batch 1M groups x 4 followers: " + label, G,
+                    APPEND_ALG + (12 * 4 + 4 if commit_rule else 0), sec,
                     dict(term_bits=dab[0]["_bits"], arena_entries=dab[0]["_terms"])))
     del dab
     torch.cuda.empty_cache()
