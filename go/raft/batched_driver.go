@@ -3,7 +3,10 @@ package raft
 import (
 	"errors"
 	"math"
+	"runtime"
 	"strconv"
+	"sync"
+	"sync/atomic"
 )
 
 // Group is one Raft group as the driver sees it: its members in slot order,
@@ -90,6 +93,45 @@ type BatchedDriver struct {
 	slots  int
 	// LastStepWide reports whether the last Step needed the 64-bit layout.
 	LastStepWide bool
+	// Step's flat images, kept between calls (176 MB at 1M x 5: allocating and
+	// zeroing them afresh costs more than the round trip over PCIe)
+	buf32 roundBuffers[int32]
+	buf64 roundBuffers[int64]
+}
+
+// parallelOverGroups runs fn(first, last) for disjoint group ranges on up to 16
+// goroutines (one call on the caller's goroutine below 32768 groups). Groups are
+// independent objects; the reference itself has no goroutines (raft.go), this
+// only concerns the flattening of its objects.
+func parallelOverGroups(groups int, fn func(g0, g1 int)) {
+	workers := 1
+	if groups >= 32768 {
+		workers = runtime.GOMAXPROCS(0)
+		if workers > 16 {
+			workers = 16
+		}
+	}
+	if workers <= 1 {
+		fn(0, groups)
+		return
+	}
+	var wg sync.WaitGroup
+	for w := 0; w < workers; w++ {
+		wg.Add(1)
+		go func(g0, g1 int) {
+			defer wg.Done()
+			fn(g0, g1)
+		}(groups*w/workers, groups*(w+1)/workers)
+	}
+	wg.Wait()
+}
+
+// sized returns s with length n, reusing its memory when it is large enough.
+func sized[E any](s []E, n int) []E {
+	if cap(s) >= n {
+		return s[:n]
+	}
+	return make([]E, n)
 }
 
 func NewBatchedDriver(device int, groups []Group, slots int, maxLogTerms uint64) (*BatchedDriver, error) {
@@ -100,21 +142,65 @@ func NewBatchedDriver(device int, groups []Group, slots int, maxLogTerms uint64)
 	return &BatchedDriver{eng: eng, groups: groups, slots: slots}, nil
 }
 
-// flatten builds the SoA image in layout L. A group without a leader gets
-// commit = the layout's maximum (N > commit is never true); a group without a
-// candidate gets the layout's belowAll term (no voter's term moves and the
-// vote outputs of such a group are not applied).
-func flatten[T word](d *BatchedDriver, L layout[T]) (*roundBuffers[T], error) {
+// flatten builds the SoA image in layout L into b (a buffer kept from the last
+// call is reused as it is: every element is written). A group without a leader
+// gets commit = the layout's maximum (N > commit is never true); a group without
+// a candidate gets the layout's belowAll term (no voter's term moves and the vote
+// outputs of such a group are not applied). Two passes over the groups, both in
+// parallel: the leaders' log lengths (then their offsets in the arena), then
+// every group's slots.
+func flatten[T word](d *BatchedDriver, L layout[T], b *roundBuffers[T]) error {
 	G, n := len(d.groups), d.slots
-	b := &roundBuffers[T]{groups: G, slots: n, ld: G}
-	plane := func() []T { return make([]T, n*G) }
-	b.match, b.voterTerm, b.votedFor, b.lastLogTerm, b.voterTermOut = plane(), plane(), plane(), plane(), plane()
-	vec := func() []T { return make([]T, G) }
-	b.commit, b.leaderTerm, b.candTerm, b.candID, b.commitOut, b.maxTerm = vec(), vec(), vec(), vec(), vec(), vec()
-	b.grantMask, b.stepdownMask = make([]uint16, G), make([]uint16, G)
-	b.elected, b.status = make([]uint8, G), make([]uint8, G)
-	b.logOff = make([]uint32, G+1)
-	b.memberMask = make([]uint16, G)
+	if n < 1 || n > 16 {
+		return errors.New("raft: a group needs 1..slots members (slots <= 16)")
+	}
+	b.groups, b.slots, b.ld, b.mixed = G, n, G, false
+	b.match, b.voterTerm, b.votedFor = sized(b.match, n*G), sized(b.voterTerm, n*G), sized(b.votedFor, n*G)
+	b.lastLogTerm, b.voterTermOut = sized(b.lastLogTerm, n*G), sized(b.voterTermOut, n*G)
+	b.commit, b.leaderTerm, b.candTerm, b.candID = sized(b.commit, G), sized(b.leaderTerm, G), sized(b.candTerm, G), sized(b.candID, G)
+	b.commitOut, b.maxTerm = sized(b.commitOut, G), sized(b.maxTerm, G)
+	b.grantMask, b.stepdownMask, b.memberMask = sized(b.grantMask, G), sized(b.stepdownMask, G), sized(b.memberMask, G)
+	b.elected, b.status = sized(b.elected, G), sized(b.status, G)
+	b.logOff = sized(b.logOff, G+1)
+	var shapeErr, rangeErr, mixed atomic.Bool
+	parallelOverGroups(G, func(g0, g1 int) {
+		for g := g0; g < g1; g++ {
+			grp := &d.groups[g]
+			if k := len(grp.Members); k < 1 || k > n {
+				shapeErr.Store(true)
+				return
+			}
+			b.logOff[g+1] = 0
+			if grp.Leader != nil {
+				if len(grp.Leader.log) > math.MaxUint32 {
+					rangeErr.Store(true)
+					return
+				}
+				b.logOff[g+1] = uint32(len(grp.Leader.log))
+			}
+		}
+	})
+	if shapeErr.Load() {
+		return errors.New("raft: a group needs 1..slots members (slots <= 16)")
+	}
+	if rangeErr.Load() {
+		return errRange
+	}
+	total := uint64(0)
+	b.logOff[0] = 0
+	for g := 0; g < G; g++ {
+		total += uint64(b.logOff[g+1])
+		if total > math.MaxUint32 {
+			return errRange
+		}
+		b.logOff[g+1] = uint32(total)
+	}
+	if total == 0 {
+		b.logTerm = sized(b.logTerm, 1)
+		b.logTerm[0] = 0
+	} else {
+		b.logTerm = sized(b.logTerm, int(total))
+	}
 	put := func(dst *T, v int) bool {
 		if !L.fits(v) {
 			return false
@@ -122,80 +208,82 @@ func flatten[T word](d *BatchedDriver, L layout[T]) (*roundBuffers[T], error) {
 		*dst = T(v)
 		return true
 	}
-	for g, grp := range d.groups {
-		k := len(grp.Members)
-		if k < 1 || k > n || n > 16 {
-			return nil, errors.New("raft: a group needs 1..slots members (slots <= 16)")
-		}
-		b.memberMask[g] = uint16(1)<<uint(k) - 1
-		if k != n {
-			b.mixed = true
-		}
-		b.commit[g], b.candTerm[g] = L.max, L.belowAll
-		if l := grp.Leader; l != nil {
-			if !put(&b.commit[g], l.commitIndex) || !put(&b.leaderTerm[g], l.currentTerm) {
-				return nil, errRange
+	parallelOverGroups(G, func(g0, g1 int) {
+		anySmall := false
+		for g := g0; g < g1; g++ {
+			grp := &d.groups[g]
+			k := len(grp.Members)
+			b.memberMask[g] = uint16(1)<<uint(k) - 1
+			anySmall = anySmall || k != n
+			b.commit[g], b.leaderTerm[g], b.candTerm[g], b.candID[g] = L.max, 0, L.belowAll, -1
+			b.commitOut[g], b.maxTerm[g], b.grantMask[g], b.stepdownMask[g], b.elected[g], b.status[g] = 0, 0, 0, 0, 0, 0
+			for p := 0; p < n; p++ {
+				i := p*G + g
+				b.match[i], b.voterTerm[i], b.votedFor[i], b.lastLogTerm[i], b.voterTermOut[i] = 0, 0, -1, L.logEmpty, 0
 			}
-			for p := 0; p < k && p < len(l.matchIndex); p++ {
-				if !put(&b.match[p*G+g], l.matchIndex[p]) {
-					return nil, errRange
+			ok := true
+			if l := grp.Leader; l != nil {
+				ok = ok && put(&b.commit[g], l.commitIndex) && put(&b.leaderTerm[g], l.currentTerm)
+				for p := 0; p < k && p < len(l.matchIndex); p++ {
+					ok = ok && put(&b.match[p*G+g], l.matchIndex[p])
+				}
+				dst := b.logTerm[b.logOff[g]:]
+				for e := range l.log {
+					ok = ok && put(&dst[e], l.log[e].TermNum)
 				}
 			}
-			for _, e := range l.log {
-				var t T
-				if !put(&t, e.TermNum) {
-					return nil, errRange
-				}
-				b.logTerm = append(b.logTerm, t)
+			if c := grp.Candidate; c != nil {
+				ok = ok && put(&b.candTerm[g], c.currentTerm) && put(&b.candID[g], c.id)
 			}
-		}
-		b.logOff[g+1] = uint32(len(b.logTerm))
-		if c := grp.Candidate; c != nil {
-			if !put(&b.candTerm[g], c.currentTerm) || !put(&b.candID[g], c.id) {
-				return nil, errRange
-			}
-		}
-		for p, m := range grp.Members {
-			i := p*G + g
-			if !put(&b.voterTerm[i], m.currentTerm) || !put(&b.votedFor[i], m.votedFor) {
-				return nil, errRange
-			}
-			b.lastLogTerm[i] = L.logEmpty
-			if len(m.log) > 0 {
-				if !put(&b.lastLogTerm[i], m.log[len(m.log)-1].TermNum) || b.lastLogTerm[i] == L.logEmpty {
-					return nil, errRange
+			for p, m := range grp.Members {
+				i := p*G + g
+				ok = ok && put(&b.voterTerm[i], m.currentTerm) && put(&b.votedFor[i], m.votedFor)
+				if len(m.log) > 0 {
+					ok = ok && put(&b.lastLogTerm[i], m.log[len(m.log)-1].TermNum) && b.lastLogTerm[i] != L.logEmpty
 				}
 			}
+			if !ok {
+				rangeErr.Store(true)
+				return
+			}
 		}
+		if anySmall {
+			mixed.Store(true)
+		}
+	})
+	if rangeErr.Load() {
+		return errRange
 	}
-	if len(b.logTerm) == 0 {
-		b.logTerm = []T{0}
-	}
-	return b, nil
+	b.mixed = mixed.Load()
+	return nil
 }
 
 // apply writes one round's decisions back: voters' terms and roles
 // (raft.go:219-221), the leader's commitIndex, and BecomeLeader for every
-// candidate that won.
+// candidate that won. Groups are independent, so the walk is parallel.
 func apply[T word](d *BatchedDriver, b *roundBuffers[T]) {
 	G := b.groups
-	for g, grp := range d.groups {
-		if grp.Candidate != nil {
-			for p, m := range grp.Members {
-				m.currentTerm = int(b.voterTermOut[p*G+g])
-				if b.stepdownMask[g]>>uint(p)&1 == 1 {
-					m.nodeType = Follower
+	parallelOverGroups(G, func(g0, g1 int) {
+		for g := g0; g < g1; g++ {
+			grp := &d.groups[g]
+			leaderBefore := grp.Leader
+			if grp.Candidate != nil {
+				for p, m := range grp.Members {
+					m.currentTerm = int(b.voterTermOut[p*G+g])
+					if b.stepdownMask[g]>>uint(p)&1 == 1 {
+						m.nodeType = Follower
+					}
+				}
+				if b.elected[g] == 1 {
+					grp.Candidate.BecomeLeader()
+					grp.Leader, grp.Candidate = grp.Candidate, nil
 				}
 			}
-			if b.elected[g] == 1 {
-				grp.Candidate.BecomeLeader()
-				d.groups[g].Leader, d.groups[g].Candidate = grp.Candidate, nil
+			if leaderBefore != nil {
+				leaderBefore.commitIndex = int(b.commitOut[g])
 			}
 		}
-		if grp.Leader != nil {
-			grp.Leader.commitIndex = int(b.commitOut[g])
-		}
-	}
+	})
 }
 
 // Step runs one fused round and applies it. The compact layout is tried first;
@@ -206,31 +294,30 @@ func apply[T word](d *BatchedDriver, b *roundBuffers[T]) {
 // RequestVoteRPC); the round is applied either way.
 //
 // Step flattens every Node and moves the whole image over PCIe both ways: fine
-// for thousands of groups, milliseconds for a million. ResidentDriver keeps the
-// image in HBM and moves only the groups the host touched.
+// for thousands of groups, tens of milliseconds for a million. ResidentDriver
+// keeps the image in HBM and moves only the groups the host touched.
 func (d *BatchedDriver) Step() error {
-	b, err := flatten(d, compact)
+	err := flatten(d, compact, &d.buf32)
 	if err == errRange {
-		w, err := flatten(d, wide)
-		if err != nil {
+		if err := flatten(d, wide, &d.buf64); err != nil {
 			return err
 		}
-		if err := d.eng.round64(w); err != nil {
+		if err := d.eng.round64(&d.buf64); err != nil {
 			return err
 		}
-		apply(d, w)
+		apply(d, &d.buf64)
 		d.LastStepWide = true
-		return flagged(w.status)
+		return flagged(d.buf64.status)
 	}
 	if err != nil {
 		return err
 	}
-	if err := d.eng.fusedRound(b); err != nil {
+	if err := d.eng.fusedRound(&d.buf32); err != nil {
 		return err
 	}
-	apply(d, b)
+	apply(d, &d.buf32)
 	d.LastStepWide = false
-	return flagged(b.status)
+	return flagged(d.buf32.status)
 }
 
 // Close releases the GPU engine.
