@@ -1636,3 +1636,53 @@ def test_append_check_with_the_follower_commit_rule(dev, wide, tiled):
         setattr(d, k, z.data_ptr())
     d.flog_terms = 1
     assert dev._l.rq_append_check_dev(dev._h, None, C.byref(d)) == -1
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_prepared_launches_under_stream_capture(dev, tiled):
+    """rq_plan_launch inside a stream capture: a replicate -> commit pipeline of prepared
+    launches (two in-place rounds of one batch, then a round of a second batch) recorded
+    once into a HIP graph and replayed; results equal the oracle applied in the same order,
+    and a replay after the inputs were restored gives them again."""
+    import torch
+    from raft_amd.device import DeviceBatch
+    G, n = 30011, 5
+    b1, b2 = synth.gen_fused(G, n, seed=301), synth.gen_fused(G, n, seed=302)
+    e1 = o.fused_round(*b1.fused_args())
+    # second in-place round of the same batch: the state the first one wrote
+    e1b = o.fused_round(b1.match, e1.commit, b1.leader_term, b1.log_off, b1.log_term, e1.voter_term,
+                        b1.voted_for, b1.last_log_term, b1.cand_term, b1.cand_id)
+    e2 = o.fused_round(*b2.fused_args())
+    d1 = DeviceBatch(b1, in_place=True, tiled=tiled, log_term_bits=0)
+    d2 = DeviceBatch(b2, tiled=tiled, log_term_bits=0)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                  # plans are built outside the capture
+        dev.fused_round(d2)
+    side.synchronize()
+    keep = d1._tile_block.clone() if tiled else {k: d1.t[k].clone() for k in ("commit", "voter_term")}
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        dev.fused_round(d1)                        # builds d1's plan; restored below
+    side.synchronize()
+
+    def restore():
+        if tiled:
+            d1._tile_block.copy_(keep)
+        else:
+            for k, v in keep.items():
+                d1.t[k].copy_(v)
+        torch.cuda.synchronize()
+    restore()
+    with torch.cuda.graph(graph, stream=side):
+        dev.fused_round(d1)
+        dev.fused_round(d1)
+        dev.fused_round(d2)
+    for _ in range(2):
+        graph.replay()
+        torch.cuda.synchronize()
+        r1, r2 = d1.results(), d2.results()
+        assert np.array_equal(r1["commit"], e1b.commit) and np.array_equal(r1["voter_term"], e1b.voter_term)
+        for f in ("grant_mask", "stepdown_mask", "elected", "max_term", "status"):
+            assert np.array_equal(r1[f], e1b[f]), f
+        _check_dev(r2, e2, G)
+        restore()
