@@ -1686,3 +1686,88 @@ def test_prepared_launches_under_stream_capture(dev, tiled):
             assert np.array_equal(r1[f], e1b[f]), f
         _check_dev(r2, e2, G)
         restore()
+
+
+def test_fuzz_append_batches(dev):
+    """Random combinations for the AppendEntries batch: group count, followers, stride,
+    adversarial indices, mask present or not, windowed follower logs, arena entry width,
+    planes or tiles, int32 or int64, terms in place or not, leader bookkeeping and the
+    follower commit rule present or not -- against the oracle on the same batch."""
+    import torch
+    from raft_amd.device import TiledAppendBatch, encode_log_terms
+    rng = np.random.default_rng(4242)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    seen = set()
+    for it in range(120):
+        n, G = int(rng.integers(1, 17)), int(rng.integers(1, 2600))
+        tiled, wide = bool(rng.integers(2)), bool(rng.integers(2))
+        ld = G if tiled else G + int(rng.choice([0, 1, 5, 64]))
+        adv, window, masked = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        in_place, books, rule = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        bits = int(rng.choice([0, 8, 16, 32]))
+        dt = np.int64 if wide else np.int32
+        b = synth.gen_append(G, n, seed=7000 + it, ld=ld, adversarial=adv)
+        if wide:
+            for k in ("follower_term", "leader_term", "prev_log_term", "flog_term"):
+                b[k] = b[k].astype(np.int64) + (1 << 40)
+            for k in ("prev_log_index", "n_new", "match_index", "next_index"):
+                b[k] = b[k].astype(np.int64)
+        if not masked:
+            del b["active_mask"]
+        if not books:
+            del b["match_index"], b["next_index"]
+        if rule:
+            b = synth.with_follower_commit(b, seed=it)
+        kw = dict(n_new=b.n_new, G=G)
+        if masked:
+            kw["active_mask"] = b.active_mask
+        if books:
+            kw.update(match_index=b.match_index, next_index=b.next_index)
+        exp = (o.append_check64 if wide else o.append_check)(
+            b.follower_term, b.leader_term, b.prev_log_index, b.prev_log_term, b.flog_off, b.flog_term, **kw)
+        exp_fc = o.append_commit(exp, b.leader_commit, b.last_new_index, b.follower_commit, n_new=b.n_new, G=G) if rule else None
+        w = synth.window_flogs(b) if window else b
+        if wide:                              # entries as differences from a per-group base term
+            w = synth.Batch(w)
+            w["flog_term_base"] = np.full(G, 1 << 40, np.int64)
+            w["flog_term"] = w["flog_term"] - (1 << 40)
+        case = (it, n, G, ld, tiled, wide, adv, window, masked, in_place, books, rule, bits)
+        if tiled:
+            tb = TiledAppendBatch(w, term_bits=bits, in_place_terms=in_place)
+            dev.append_check(tb.t, G, n, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=tb.wide)
+            got = {k: tb.fetch(k) for k in ("success_mask", "stepdown_mask", "status")}
+            got["follower_term"] = tb.fetch("follower_term_out").reshape(n, G)
+            for k in (("match_index", "next_index") if books else ()) + (("follower_commit",) if rule else ()):
+                got[k] = tb.fetch(k).reshape(n, G)
+        else:
+            enc, ebits, _ = encode_log_terms(w.flog_term, bits=bits)
+            t = {k: up(w[k]) for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new")}
+            for k in ("match_index", "next_index", "flog_base", "flog_term_base", "leader_commit", "last_new_index",
+                      "follower_commit"):
+                if k in w:
+                    t[k] = up(w[k])
+            if masked:
+                t["active_mask"] = up(w.active_mask.view(np.int16))
+            t["flog_off"] = up(w.flog_off.view(np.int32))
+            t["flog_term"] = up(enc if enc.size else np.zeros(1, enc.dtype))
+            t["follower_term_out"] = t["follower_term"] if in_place else t["follower_term"].clone()
+            t["success_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
+            t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
+            t["status"] = torch.zeros(G, dtype=torch.uint8, device="cuda:0")
+            dev.append_check(t, G, n, ld, flog_term_bits=ebits, flog_terms=int(enc.size), wide=wide)
+            torch.cuda.synchronize()
+            got = {k: t[k].cpu().numpy() for k in ("success_mask", "stepdown_mask", "status")}
+            got["follower_term"] = t["follower_term_out"].cpu().numpy()[:, :G]
+            for k in (("match_index", "next_index") if books else ()) + (("follower_commit",) if rule else ()):
+                got[k] = t[k].cpu().numpy()[:, :G]
+        assert np.array_equal(got["success_mask"].view(np.uint16), exp["success_mask"][:G]), case
+        assert np.array_equal(got["stepdown_mask"].view(np.uint16), exp["stepdown_mask"][:G]), case
+        assert np.array_equal(got["status"], exp["status"][:G]), case
+        assert np.array_equal(got["follower_term"], exp["follower_term"][:, :G]), case
+        if books:
+            assert np.array_equal(got["match_index"], exp["match_index"][:, :G]), case
+            assert np.array_equal(got["next_index"], exp["next_index"][:, :G]), case
+        if rule:
+            assert np.array_equal(got["follower_commit"], exp_fc[:, :G]), case
+        seen.add((tiled, wide, rule))
+    assert len(seen) == 8
