@@ -158,6 +158,19 @@ class TiledAppendBatch:
         self.t["_tile_bytes"], self.t["_out_tile_bytes"] = self.tile_bytes, self.out_tile_bytes
         self.wide = vdt == np.int64
 
+    def store(self, name, a):
+        """Overwrite array `name` inside the tiles with host array a ([slots][>= G] or [>= G])."""
+        is_out, o, slots, dt = self._place[name]
+        blk = self._out if is_out else self._in
+        stride = self.out_tile_bytes if is_out else self.tile_bytes
+        ntiles = blk.numel() // stride
+        a = np.asarray(a, dtype=dt).reshape(slots, -1)[:, : self.G]
+        pad = np.zeros((slots, ntiles * 64), dt)
+        pad[:, : self.G] = a
+        tiles = np.ascontiguousarray(pad.reshape(slots, ntiles, 64).transpose(1, 0, 2)).reshape(ntiles, -1)
+        view = blk.view(ntiles, stride)[:, o: o + slots * 64 * dt.itemsize]
+        view.copy_(torch.from_numpy(tiles.view(np.uint8)).to(self.device))
+
     def fetch(self, name):
         is_out, o, slots, dt = self._place[name]
         torch.cuda.synchronize(self.device)

@@ -1771,3 +1771,63 @@ def test_fuzz_append_batches(dev):
             assert np.array_equal(got["follower_commit"], exp_fc[:, :G]), case
         seen.add((tiled, wide, rule))
     assert len(seen) == 8
+
+
+def test_replication_rounds_stay_on_the_device(dev):
+    """Four rounds of replicate -> leader commit -> follower commit on ONE tiled image with
+    nothing but each round's RPC arguments going up: the AppendEntries batch updates matchIndex
+    and applies raft.go:172-176 with the leaders' commitIndex array as leaderCommit, the commit
+    round advances that same array in place.  Every array after every round against the
+    oracle run in the same order."""
+    import ctypes as C
+    import torch
+    from raft_amd import _lib
+    from raft_amd.device import TiledAppendBatch, encode_log_terms
+    G, n = 20011, 4
+    b = synth.with_follower_commit(synth.gen_append(G, n, seed=411), seed=3)
+    del b["active_mask"]
+    c = synth.gen_fused(G, n, seed=17)                     # the leaders' logs and commitIndex
+    b["leader_commit"] = c.commit[:G].copy()
+    b["leader_term"] = c.leader_term[:G].copy()            # one term per group for both steps
+    b["follower_term"] = np.minimum(b.follower_term, b.leader_term[None, :] + 1).astype(np.int32)
+    tb = TiledAppendBatch(b, extra_in=dict(log_off=c.log_off.view(np.int32)),
+                          extra_out=[("round_status", 1, np.uint8)])
+    arena, bits, _ = encode_log_terms(c.log_term, bits=0)
+    log_term = torch.from_numpy(arena).to("cuda:0")
+    d = _lib.RoundDesc()
+    d.struct_size = C.sizeof(_lib.RoundDesc)
+    d.layout, d.what, d.G, d.n = 4, 1, G, n
+    d.tile_bytes, d.out_tile_bytes = tb.tile_bytes, tb.out_tile_bytes
+    d.match = tb.t["match_index"].data_ptr()
+    d.commit = d.commit_out = tb.t["leader_commit"].data_ptr()          # advanced in place
+    d.leader_term = tb.t["leader_term"].data_ptr()
+    d.log_off, d.log_term = tb.t["log_off"].data_ptr(), log_term.data_ptr()
+    d.log_terms, d.log_term_bits = int(c.log_term.size), bits
+    d.status_out = tb.t["round_status"].data_ptr()
+    off = b.flog_off.astype(np.int64)
+    lens = np.diff(off).reshape(n, G)
+    rng = np.random.default_rng(8)
+    ft, mi, ni = b.follower_term.copy(), b.match_index.copy(), b.next_index.copy()
+    fc, lc = b.follower_commit.copy(), b.leader_commit.copy()
+    advanced = clamped = 0
+    for r in range(4):
+        pi = (rng.random((n, G)) * np.maximum(lens, 1)).astype(np.int32)
+        at = np.minimum(off[:-1].reshape(n, G) + pi, max(b.flog_term.size - 1, 0))
+        pt = (b.flog_term[at] + (rng.random((n, G)) < 0.2)).astype(np.int32)
+        nn = rng.integers(0, 4, (n, G)).astype(np.int32)
+        li = (pi + nn).astype(np.int32)
+        for k, a in (("prev_log_index", pi), ("prev_log_term", pt), ("n_new", nn), ("last_new_index", li)):
+            tb.store(k, a)
+        dev.append_check(tb.t, G, n, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=False)
+        assert dev._l.rq_round_dev(dev._h, torch.cuda.current_stream().cuda_stream, C.byref(d)) == 0
+        exp = o.append_check(ft, b.leader_term, pi, pt, b.flog_off, b.flog_term, n_new=nn, match_index=mi, next_index=ni)
+        fc2 = o.append_commit(exp, lc, li, fc, n_new=nn)
+        lc2, st = o.commit_advance(exp["match_index"], lc, b.leader_term, c.log_off, c.log_term)
+        clamped += int((fc2 != fc).sum()); advanced += int((lc2 != lc).sum())
+        ft, mi, ni, fc, lc = exp["follower_term"], exp["match_index"], exp["next_index"], fc2, lc2
+        assert np.array_equal(tb.fetch("follower_term"), ft) and np.array_equal(tb.fetch("match_index"), mi), r
+        assert np.array_equal(tb.fetch("next_index"), ni) and np.array_equal(tb.fetch("follower_commit"), fc), r
+        assert np.array_equal(tb.fetch("leader_commit"), lc) and np.array_equal(tb.fetch("round_status"), st), r
+        assert np.array_equal(tb.fetch("status"), exp["status"]) and np.array_equal(
+            tb.fetch("success_mask").view(np.uint16), exp["success_mask"]), r
+    assert advanced > G // 20 and clamped > G // 5
