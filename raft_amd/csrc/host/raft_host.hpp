@@ -190,7 +190,10 @@ private:
 // uploads those groups only (rq_groups_scatter_dev), runs the round in place
 // (rq_plan_launch), reads the one-bit-per-group "changed" summary the kernel
 // wrote and downloads and applies only the groups whose bit is set
-// (rq_groups_gather_dev).  Staging lives in page-locked memory allocated once.
+// (rq_groups_gather_dev).  The image is laid out in the 64-group tiles of
+// rq_round_desc.tile_bytes (the layout the round kernels run fastest on; the
+// single-group calls address it like planes).  Staging lives in page-locked
+// memory allocated once.
 // Compact (int32) layout; values beyond it make Rebuild fail with RQ_E_RANGE and
 // the caller falls back to BatchedDriver.
 class ResidentDriver {

@@ -147,10 +147,29 @@ int ResidentDriver::Rebuild() {
     }
     I.release();
     I.G = G; I.n = n;
-    const size_t ld = G, plane = (size_t)n * ld, words = 4 * (size_t)n + 7;
-    std::vector<int32_t> match(plane), vt(plane), vf(plane), ll(plane), commit(G), lterm(G), cterm(G), cid(G), arena;
+    const size_t words = 4 * (size_t)n + 7;
+    // The image lives in the 64-group tiles of rq_round_desc.tile_bytes: one block for the
+    // inputs (and the state updated in place), one for the pure outputs.  Field offsets
+    // inside a tile, widest elements first:
+    const uint64_t slot4 = (uint64_t)n * 256;                    // n slots x 64 groups x 4 bytes
+    const uint64_t o_match = 0, o_vt = slot4, o_vf = 2 * slot4, o_ll = 3 * slot4;
+    const uint64_t o_commit = 4 * slot4, o_lterm = o_commit + 256, o_cterm = o_lterm + 256, o_cid = o_cterm + 256;
+    const uint64_t o_len = o_cid + 256, o_aux = o_len + 256;      // aux: log_off, or log_term_start without an arena
+    const uint64_t o_om = o_aux + 256, o_nm = o_om + 128;
+    const uint64_t tile_bytes = o_nm + 128;
+    const uint64_t oo_max = 0, oo_grant = 256, oo_step = 384, oo_elected = 512, oo_status = 576;
+    const uint64_t out_tile_bytes = 768;
+    const uint64_t ntiles = ((uint64_t)G + 1 + 63) / 64;         // log_off has G + 1 entries
+    std::vector<unsigned char> block(ntiles * tile_bytes, 0);
+    auto w32 = [&](uint64_t off, uint32_t p, uint32_t g) -> int32_t & {
+        return *reinterpret_cast<int32_t *>(block.data() + (uint64_t)(g >> 6) * tile_bytes + off +
+                                            ((uint64_t)p * 64 + (g & 63u)) * 4);
+    };
+    auto w16 = [&](uint64_t off, uint32_t g) -> uint16_t & {
+        return *reinterpret_cast<uint16_t *>(block.data() + (uint64_t)(g >> 6) * tile_bytes + off + (uint64_t)(g & 63u) * 2);
+    };
+    std::vector<int32_t> arena;
     std::vector<uint32_t> len(G);
-    std::vector<uint16_t> om(G), nm(G);
     I.off.assign((size_t)G + 1, 0);
     I.cap.assign(G, 0);
     mixed_ = false;
@@ -185,20 +204,26 @@ int ResidentDriver::Rebuild() {
             if (rc == RQ_OK && !I.by_start && terms.size() > I.cap[g]) rc = RQ_E_ARG;
             if (rc != RQ_OK) { err.store(rc); return; }
             for (uint32_t p = 0; p < n; p++) {
-                match[p * ld + g] = row[p]; vt[p * ld + g] = row[n + p];
-                vf[p * ld + g] = row[2 * n + p]; ll[p * ld + g] = row[3 * n + p];
+                w32(o_match, p, g) = row[p]; w32(o_vt, p, g) = row[n + p];
+                w32(o_vf, p, g) = row[2 * n + p]; w32(o_ll, p, g) = row[3 * n + p];
             }
             const int32_t *tail = row.data() + 4 * n;
-            commit[g] = tail[0]; lterm[g] = tail[1]; cterm[g] = tail[2]; cid[g] = tail[3];
-            om[g] = (uint16_t)((uint32_t)tail[5] & 0xFFFFu); nm[g] = (uint16_t)((uint32_t)tail[5] >> 16);
+            w32(o_commit, 0, g) = tail[0]; w32(o_lterm, 0, g) = tail[1];
+            w32(o_cterm, 0, g) = tail[2]; w32(o_cid, 0, g) = tail[3];
+            w16(o_om, g) = (uint16_t)((uint32_t)tail[5] & 0xFFFFu); w16(o_nm, g) = (uint16_t)((uint32_t)tail[5] >> 16);
             if (groups_[g].Members.size() != n) mixed.store(true);
-            if (!I.by_start) {
+            if (I.by_start) {
+                w32(o_aux, 0, g) = tstart[g];
+            } else {
                 len[g] = (uint32_t)terms.size();
                 std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * 4);
+                w32(o_aux, 0, g) = (int32_t)I.off[g];
             }
+            w32(o_len, 0, g) = (int32_t)len[g];
         }
     });
     if (err.load() != RQ_OK) return err.load();
+    if (!I.by_start) w32(o_aux, 0, G) = (int32_t)I.off[G];
     mixed_ = mixed.load();
     // free space behind the slices: logs that outgrow their slice move there
     I.tail = arena.size();
@@ -210,42 +235,39 @@ int ResidentDriver::Rebuild() {
     rq_round_desc &d = I.desc;
     std::memset(&d, 0, sizeof d);
     d.struct_size = sizeof d; d.layout = RQ_LAYOUT_I32; d.what = RQ_ROUND_COMMIT | RQ_ROUND_VOTE;
-    d.G = G; d.n = n; d.ld = (uint32_t)ld; d.log_terms = arena.size();
-    void *p = nullptr;
-    auto upload = [&](const void *src, uint64_t bytes, const void **field) {
-        int rc = I.dalloc(bytes, &p);
-        if (rc == RQ_OK) rc = rq_copy_to_device(I.e, p, src, bytes);
-        *field = p;
-        return rc;
-    };
+    d.G = G; d.n = n; d.ld = G; d.log_terms = arena.size();
+    d.tile_bytes = tile_bytes; d.out_tile_bytes = out_tile_bytes;
 #define RH_TRY(x) do { int rh_rc_ = (x); if (rh_rc_ != RQ_OK) return rh_rc_; } while (0)
-    RH_TRY(upload(match.data(), plane * 4, &d.match));
-    RH_TRY(upload(vt.data(), plane * 4, &d.voter_term));
-    RH_TRY(upload(vf.data(), plane * 4, &d.voted_for));
-    RH_TRY(upload(ll.data(), plane * 4, &d.voter_last_log_term));
-    RH_TRY(upload(commit.data(), (uint64_t)G * 4, &d.commit));
-    if (!I.by_start) RH_TRY(upload(lterm.data(), (uint64_t)G * 4, &d.leader_term));
-    RH_TRY(upload(cterm.data(), (uint64_t)G * 4, &d.cand_term));
-    RH_TRY(upload(cid.data(), (uint64_t)G * 4, &d.cand_id));
-    RH_TRY(upload(len.data(), (uint64_t)G * 4, (const void **)&d.log_len));
+    char *in_dev = nullptr, *out_dev = nullptr;
+    RH_TRY(I.dalloc(block.size(), (void **)&in_dev));
+    RH_TRY(rq_copy_to_device(I.e, in_dev, block.data(), block.size()));
+    RH_TRY(I.dalloc(ntiles * out_tile_bytes, (void **)&out_dev));
+    d.match = in_dev + o_match; d.voter_term = in_dev + o_vt; d.voted_for = in_dev + o_vf;
+    d.voter_last_log_term = in_dev + o_ll;
+    d.commit = in_dev + o_commit; d.cand_term = in_dev + o_cterm; d.cand_id = in_dev + o_cid;
+    d.log_len = (const uint32_t *)(in_dev + o_len);
     if (I.by_start) {
-        RH_TRY(upload(tstart.data(), (uint64_t)G * 4, &d.log_term_start));
+        d.log_term_start = in_dev + o_aux;
     } else {
-        RH_TRY(upload(I.off.data(), ((uint64_t)G + 1) * 4, (const void **)&d.log_off));
-        RH_TRY(upload(arena.data(), (uint64_t)arena.size() * 4, &d.log_term));
+        d.leader_term = in_dev + o_lterm;
+        d.log_off = (const uint32_t *)(in_dev + o_aux);
+        void *arena_dev = nullptr;
+        RH_TRY(I.dalloc((uint64_t)arena.size() * 4, &arena_dev));
+        RH_TRY(rq_copy_to_device(I.e, arena_dev, arena.data(), (uint64_t)arena.size() * 4));
+        d.log_term = arena_dev;
     }
     if (mixed_) {
-        RH_TRY(upload(om.data(), (uint64_t)G * 2, (const void **)&d.old_mask));
-        RH_TRY(upload(nm.data(), (uint64_t)G * 2, (const void **)&d.new_mask));
+        d.old_mask = (const uint16_t *)(in_dev + o_om);
+        d.new_mask = (const uint16_t *)(in_dev + o_nm);
     }
     // state is updated in place between rounds, as the host applies it to its Nodes
     d.commit_out = const_cast<void *>(d.commit);
     d.voter_term_out = const_cast<void *>(d.voter_term);
-    RH_TRY(I.dalloc((uint64_t)G * 2, (void **)&d.grant_mask));
-    RH_TRY(I.dalloc((uint64_t)G * 2, (void **)&d.stepdown_mask));
-    RH_TRY(I.dalloc(G, (void **)&d.elected));
-    RH_TRY(I.dalloc((uint64_t)G * 4, &d.max_term));
-    RH_TRY(I.dalloc(G, (void **)&d.status_out));
+    d.max_term = out_dev + oo_max;
+    d.grant_mask = (uint16_t *)(out_dev + oo_grant);
+    d.stepdown_mask = (uint16_t *)(out_dev + oo_step);
+    d.elected = (uint8_t *)(out_dev + oo_elected);
+    d.status_out = (uint8_t *)(out_dev + oo_status);
     const uint64_t bit_words = ((uint64_t)G + 63) / 64;
     RH_TRY(I.dalloc(bit_words * 8, (void **)&d.changed_bits));
     RH_TRY(rq_plan_round(I.e, &d, &I.plan));
