@@ -310,6 +310,44 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
     cbytes = abytes + 12 * (n - 1) + 4
     out["append_check_commit"] = dict(kernel_ms=ms, frac=frac(cbytes, ms), input_sets=A, alg_bytes_per_group=cbytes,
                                       note="AppendEntries batch + follower commit rule in one launch")
+    # replicate -> commit: the batch followed by the commit round over the matchIndex array it
+    # has just updated (n - 1 followers + the leader's own slot), as two launches and with the
+    # leader's commit rule decided inside the batch's launch (rq_append_desc.commit_round)
+    import ctypes as C
+    from raft_amd import _lib
+    for s, t in enumerate(asets):
+        for k in ("leader_commit", "last_new_index", "follower_commit"):
+            del t[k]
+        c = host_batches[s]
+        arena, cbits, _ = encode_log_terms(c.log_term, bits=0)
+        t["match_index"] = torch.cat([t["match_index"], up(c.match[n - 1:n, :G])])
+        t["leader_term"] = up(c.leader_term[:G])
+        t["commit"], t["commit_out"] = up(c.commit[:G]), torch.zeros(G, dtype=torch.int32, device=device)
+        t["log_off"], t["log_term"] = up(c.log_off.view(np.int32)), up(arena)
+        t["round_status"] = torch.zeros(G, dtype=torch.uint8, device=device)
+        d = _lib.RoundDesc()
+        d.struct_size = C.sizeof(_lib.RoundDesc)
+        d.layout, d.what, d.G, d.n, d.ld = 4, 1, G, n, G
+        d.match, d.commit, d.leader_term = t["match_index"].data_ptr(), t["commit"].data_ptr(), t["leader_term"].data_ptr()
+        d.log_off, d.log_term = t["log_off"].data_ptr(), t["log_term"].data_ptr()
+        d.log_terms, d.log_term_bits = int(arena.size), cbits
+        d.commit_out, d.status_out = t["commit_out"].data_ptr(), t["round_status"].data_ptr()
+        t["_round"] = d
+
+    def two_launches(i):
+        t = asets[i % A]
+        eng.append_check(t, G, n - 1, G, flog_term_bits=t["_bits"], flog_terms=t["_terms"])
+        eng._check(eng._l.rq_round_dev(eng._h, torch.cuda.current_stream().cuda_stream, C.byref(t["_round"])), "rq_round_dev")
+
+    ms2 = timed_launches(torch, device, two_launches, steps, warmup, A)
+    ms1 = timed_launches(torch, device, lambda i: eng.append_check(
+        asets[i % A], G, n - 1, G, flog_term_bits=asets[i % A]["_bits"], flog_terms=asets[i % A]["_terms"],
+        commit_round=asets[i % A]["_round"]), steps, warmup, A)
+    rbytes = abytes + alg_bytes_per_group(n, "commit")
+    out["replicate_commit"] = dict(kernel_ms=ms1, frac=frac(rbytes, ms1), two_launches_ms=ms2, frac_two_launches=frac(rbytes, ms2),
+                                   input_sets=A, alg_bytes_per_group=rbytes,
+                                   note="AppendEntries batch + leader commit rule: one launch (commit_round) against two; "
+                                        "bytes priced as for the two launches")
     del asets
     torch.cuda.empty_cache()
 

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RQ_VERSION 0x000203 /* 0.2.3: rq_append_desc gained the follower commit clamp (leader_commit, last_new_index, follower_commit_io) */
+#define RQ_VERSION 0x000204 /* 0.2.4: rq_append_desc gained the follower commit clamp (leader_commit, last_new_index, follower_commit_io) and commit_round */
 
 /* return codes */
 #define RQ_OK            0
@@ -426,7 +426,18 @@ int rq_plan_destroy(rq_plan *p);
  *                   the reference's lastEntry(newEntries) panic (:175, :235):
  *                   RQ_ST_EMPTY_LOG, commitIndex unchanged.  Other slots keep their
  *                   commitIndex.  The steps between (:158-170, the log mutation) stay
- *                   with the host, which also vouches that they do not panic. */
+ *                   with the host, which also vouches that they do not panic.
+ *   commit_round    NULL, or the descriptor of the COMMIT round (what = RQ_ROUND_COMMIT,
+ *                   same layout, G and tiling / ld) that would follow this batch on the
+ *                   same image: its `match` must BE match_index_io, its n the batch's n
+ *                   (the followers' slots) or n + 1 (the leader's own slot after them).
+ *                   The leader's commit rule is then decided in this launch from the
+ *                   matchIndex values still in registers -- same results as
+ *                   rq_append_check_dev followed by rq_round_dev(commit_round), one
+ *                   launch and 20 bytes per group less.  The round's log arena options
+ *                   (log_term_bits, log_term_base, log_base, log_len, log_term_start),
+ *                   commit_out (may be commit) and status_out apply; member masks,
+ *                   summaries, bit outputs and start_signal must be NULL there. */
 typedef struct rq_append_desc {
     uint32_t struct_size;       /* sizeof(rq_append_desc) */
     uint32_t layout;            /* RQ_LAYOUT_I32 or RQ_LAYOUT_I64 */
@@ -444,6 +455,7 @@ typedef struct rq_append_desc {
     uint64_t tile_bytes, out_tile_bytes;
     const void *leader_commit, *last_new_index;
     void *follower_commit_io;
+    const rq_round_desc *commit_round;
 } rq_append_desc;
 int rq_append_check_dev(rq_engine *e, void *stream, const rq_append_desc *d);
 

@@ -49,7 +49,8 @@ class AppendDesc(C.Structure):
                 ("follower_term_out", vp), ("success_mask", vp), ("stepdown_mask", vp),
                 ("match_index_io", vp), ("next_index_io", vp), ("status_out", vp),
                 ("tile_bytes", u64), ("out_tile_bytes", u64),
-                ("leader_commit", vp), ("last_new_index", vp), ("follower_commit_io", vp)]
+                ("leader_commit", vp), ("last_new_index", vp), ("follower_commit_io", vp),
+                ("commit_round", vp)]
 
 
 _COMMIT_IN = [i32p, i32p, i32p, u32p, i32p]          # match commit leader_term log_off log_term

@@ -35,10 +35,75 @@ __device__ __forceinline__ size_t append_index(uint64_t tile_bytes, size_t ld, u
     else return (size_t)p * ld + g;
 }
 
+// The leader's commit rule in the same launch (rq_append_desc.commit_round): what a commit
+// round over the batch's matchIndex array would read back from memory right after this batch
+// is still in registers here.  r describes that round (its `match` IS match_index_io; its
+// slots are the batch's follower slots, optionally followed by the leader's own); the
+// decision is the round kernels' -- quorum index of the r.m values, N > commitIndex, log[N]
+// inside the log and of the leader's term (or N >= log_term_start) -- with the sort done by
+// the member-mask round's network over r.m live values.
+template <typename T>
+struct commit_inputs {
+    T cm, lt, lb, tb, ts;
+    uint32_t beg, end, ln;
+};
+template <typename T>
+__device__ __forceinline__ commit_inputs<T> load_commit_inputs(const rq_round_args_t<T> &r, uint32_t g) {
+    commit_inputs<T> in;
+    const group_addr ga = addr_of(r, g);
+    in.lt = 0; in.lb = 0; in.tb = 0; in.ts = 0; in.beg = 0; in.end = 0; in.ln = 0;
+    in.cm = __builtin_nontemporal_load(at(r.commit, ga));
+    if (r.log_base) in.lb = __builtin_nontemporal_load(at(r.log_base, ga));
+    if (r.log_len) in.ln = __builtin_nontemporal_load(at(r.log_len, ga));
+    if (r.log_term_start) {
+        in.ts = __builtin_nontemporal_load(at(r.log_term_start, ga));
+    } else {
+        in.lt = __builtin_nontemporal_load(at(r.leader_term, ga));
+        if (r.log_term_base) in.tb = __builtin_nontemporal_load(at(r.log_term_base, ga));
+        in.beg = __builtin_nontemporal_load(at(r.log_off, ga));
+        in.end = *at(r.log_off, addr_of(r, g + 1));
+    }
+    return in;
+}
+// Quorum index of the first n of the L values in v (n = L - 1 or L): the member-mask round's
+// descending network over 8 or 16 inputs, the inputs beyond L being compile-time fillers.
+template <int L, typename T>
+__device__ __forceinline__ T live_quorum(const T (&v)[L], uint32_t n) {
+    constexpr int W = L > 8 ? 16 : 8;
+    T s[W];
+#pragma unroll
+    for (int p = 0; p < W; p++) s[p] = kMinOf<T>;
+#pragma unroll
+    for (int p = 0; p < L; p++) s[p] = (uint32_t)p < n ? v[p] : kMinOf<T>;
+    if constexpr (W == 8) sort_desc8(s); else sort_desc16(s);
+    const int idx = (int)(n >> 1);
+    T q = s[0];
+#pragma unroll
+    for (int i = 1; i <= W / 2; i++) q = (idx == i) ? s[i] : q;
+    return q;
+}
+template <typename T>
+__device__ __forceinline__ T commit_decision(const rq_round_args_t<T> &r, const commit_inputs<T> &in, T nq,
+                                             uint32_t &st) {
+    typedef typename std::make_unsigned<T>::type U;
+    const bool by_start = r.log_term_start != nullptr;
+    const bool csr = by_start || (r.log_len ? span_ok(in.beg, in.ln, r.log_terms) : slice_ok(in.beg, in.end, r.log_terms));
+    const uint32_t len = r.log_len ? in.ln : in.end - in.beg;
+    const U wi = window_slot(nq, in.lb);
+    const bool adv = nq > in.cm, inb = csr && wi < (U)len;
+    st |= csr ? 0u : kStBadCsr;
+    st |= (adv && !inb) ? kStLogOob : 0u;
+    bool hit = by_start ? nq >= in.ts : false;
+    if (!by_start && adv && inb)
+        hit = (T)((U)load_term<true, T>(r.log_term, r.log_term_bits, (size_t)in.beg + (size_t)wi) + (U)in.tb) == in.lt;
+    return (adv && inb && hit) ? nq : in.cm;
+}
+
 // CLAMP: the follower commit rule is part of the launch (a build of its own: its two extra
-// planes per slot would otherwise cost every launch 12 registers per slot).
-template <int NMAX, bool TILED, bool CLAMP, typename T>
-__global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_t<T> a) {
+// planes per slot would otherwise cost every launch 12 registers per slot).  COMMIT: the
+// leader's commit rule as well (r is only read then).
+template <int NMAX, bool TILED, bool CLAMP, bool COMMIT, typename T>
+__global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_t<T> a, rq_round_args_t<T> r) {
     typedef typename std::make_unsigned<T>::type U;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.G) return;
@@ -74,7 +139,19 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
                 fc[p] = __builtin_nontemporal_load(a.follower_commit_io + s);
                 li[p] = __builtin_nontemporal_load(a.last_new_index + s);
             }
+        } else if constexpr (COMMIT) {
+            // a slot without an RPC still counts in the commit round: its stored matchIndex
+            if ((uint32_t)p < r.m) mi[p] = __builtin_nontemporal_load(a.match_index_io + append_index<TILED, T>(a.tile_bytes, ld, g, p));
         }
+    }
+    // COMMIT: matchIndex of every slot the commit round counts -- what this batch produces
+    // stays in registers, the rest (slots without an RPC; the leader's own slot, read at the
+    // end) was loaded above with the batch's own planes
+    constexpr int L = NMAX < 16 ? NMAX + 1 : 16;
+    T mv[L];
+    if constexpr (COMMIT) {
+#pragma unroll
+        for (int p = 0; p < L; p++) mv[p] = p < NMAX ? mi[p] : (T)0;
     }
     uint32_t reach = 0, inb = 0, bad = 0;
 #pragma unroll
@@ -111,6 +188,7 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
             else if (r) { n2 = n2 > 1 ? n2 - 1 : 1; }
             if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
             if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
+            if constexpr (COMMIT) { if (a.match_index_io) mv[p] = m2; }
         }
         if constexpr (clamp) {
             T c2 = fc[p];
@@ -125,6 +203,22 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     __builtin_nontemporal_store((uint16_t)ok, a.success_mask + g16);
     __builtin_nontemporal_store((uint16_t)sd, a.stepdown_mask + g16);
     if (a.status_out) a.status_out[append_index<TILED, uint8_t>(out_tile, ld, g, 0)] = (uint8_t)st;
+    if constexpr (COMMIT) {
+        // the round's own inputs are read here, after the batch's stores: issued with the batch's
+        // planes they cost 40 registers and half the resident waves
+        const group_addr rga = addr_of(r, g);
+        group_addr rgo = rga;                     // the round's outputs: their own tile block unless in place
+        if (r.tile_bytes) rgo.tile_off = (size_t)(g >> 6) * r.out_tile_bytes;
+        const group_addr gco = (const void *)r.commit_out == (const void *)r.commit ? rga : rgo;
+        if constexpr (L > NMAX) {
+            if (r.m > (uint32_t)NMAX) mv[NMAX] = __builtin_nontemporal_load(at(r.match, rga, NMAX));
+        }
+        const commit_inputs<T> cin = load_commit_inputs(r, g);
+        uint32_t rst = 0;
+        const T co = commit_decision(r, cin, live_quorum<L>(mv, r.m), rst);
+        __builtin_nontemporal_store(co, at(r.commit_out, gco));
+        if (r.status_out) *at(r.status_out, rgo) = (uint8_t)rst;
+    }
 }
 
 // raft.go:172-176 elementwise
@@ -153,7 +247,8 @@ __global__ __launch_bounds__(kBlock) void rq_follower_clamp_kernel(
 
 
 template <typename T>
-hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, hipStream_t stream) {
+hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, const rq_round_args_t<T> *commit_round,
+                                    hipStream_t stream) {
     if (a.G == 0) return hipSuccess;
     if (a.G > 0x7FFFFFFFu || (a.ld < a.G && !a.tile_bytes) || a.n < 1 || a.n > 16) return hipErrorInvalidValue;
     if ((a.tile_bytes & 7u) || (a.out_tile_bytes & 7u) || ((a.tile_bytes != 0) != (a.out_tile_bytes != 0))) return hipErrorInvalidValue;
@@ -164,8 +259,26 @@ hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, hipStream_t st
     const int clamp_ptrs = (a.leader_commit != nullptr) + (a.last_new_index != nullptr) + (a.follower_commit_io != nullptr);
     if (clamp_ptrs != 0 && clamp_ptrs != 3) return hipErrorInvalidValue;
     const bool clamp = clamp_ptrs == 3, tiled = a.tile_bytes != 0;
-#define RQ_APPEND_LAUNCH(N, TILED, CLAMP) \
-    hipLaunchKernelGGL((rq_append_check_kernel<N, TILED, CLAMP, T>), grid, blk, 0, stream, a)
+    rq_round_args_t<T> r = rq_round_args_t<T>();      // zeroed
+    if (commit_round) {
+        r = *commit_round;
+        // the round reads the array this batch updates, in the same arrangement, and nothing else of it is fused
+        if (r.G != a.G || r.m < a.n || r.m > a.n + 1 || r.m > 16 || r.tile_bytes != a.tile_bytes ||
+            (!r.tile_bytes && r.ld != a.ld) || (const void *)r.match != (const void *)a.match_index_io ||
+            !a.match_index_io || r.old_mask || r.commit_lo16 || r.changed_bits || r.elected_bits || r.start_signal ||
+            !r.commit || !r.commit_out)
+            return hipErrorInvalidValue;
+        if (r.log_term_start ? !r.log_len : (!r.leader_term || !r.log_off || (!r.log_term && r.log_terms)))
+            return hipErrorInvalidValue;
+        const uint32_t rb = r.log_term_bits;
+        if (rb != 8 && rb != 16 && rb != 32 && rb != 8 * sizeof(T)) return hipErrorInvalidValue;
+    }
+    const bool commit = commit_round != nullptr;
+#define RQ_APPEND_LAUNCH(N, TILED, CLAMP)                                                                        \
+    do {                                                                                                         \
+        if (commit) hipLaunchKernelGGL((rq_append_check_kernel<N, TILED, CLAMP, true, T>), grid, blk, 0, stream, a, r); \
+        else hipLaunchKernelGGL((rq_append_check_kernel<N, TILED, CLAMP, false, T>), grid, blk, 0, stream, a, r);      \
+    } while (0)
 #define RQ_APPEND_CASE(N)                                             \
     case N:                                                           \
         if (tiled && clamp) RQ_APPEND_LAUNCH(N, true, true);          \

@@ -455,7 +455,7 @@ int append_check_host(rq_engine *e, const rq_append_args_t<T> &h) {
     a.match_index_io = h.match_index_io ? d_mi : nullptr;
     a.next_index_io = h.next_index_io ? d_ni : nullptr;
     a.status_out = d_st;
-    RQ_HIP(e, rq_launch_append_check(a, e->stream));
+    RQ_HIP(e, rq_launch_append_check(a, nullptr, e->stream));
     RQ_TRY(d2h(e, h.follower_term_out, d_fo, slots * E));
     RQ_TRY(d2h(e, h.success_mask, d_ok, (size_t)G * 2));
     RQ_TRY(d2h(e, h.stepdown_mask, d_sd, (size_t)G * 2));
@@ -486,8 +486,16 @@ int append_check_dev(rq_engine *e, void *stream, const rq_append_desc &d) {
     if (a.flog_term_bits > 8 * sizeof(T) || d.flog_terms > 0xFFFFFFFFull) return RQ_E_ARG;
     if (!a.flog_term && d.flog_terms == 0) a.flog_term = a.flog_off;   // empty arena: never dereferenced
     RQ_TRY(append_args_ok(a));
+    rq_round_args_t<T> r;
+    const rq_round_args_t<T> *rp = nullptr;
+    if (d.commit_round) {                          // the leader's commit rule in the same launch
+        const rq_round_desc &c = *d.commit_round;
+        if (c.struct_size != sizeof(rq_round_desc) || c.layout != d.layout || c.what != RQ_ROUND_COMMIT) return RQ_E_ARG;
+        RQ_TRY(round_args_from_desc(c, r));
+        rp = &r;
+    }
     RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = rq_launch_append_check(a, (hipStream_t)stream);
+    hipError_t err = rq_launch_append_check(a, rp, (hipStream_t)stream);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;

@@ -129,8 +129,10 @@ struct rq_append_args_t {
 };
 typedef rq_append_args_t<int32_t> rq_append_args;
 typedef rq_append_args_t<int64_t> rq_append64_args;
-hipError_t rq_launch_append_check(const rq_append_args &a, hipStream_t stream);
-hipError_t rq_launch_append_check(const rq_append64_args &a, hipStream_t stream);
+// commit_round: null, or the commit round to decide in the same launch (its match array is
+// the batch's match_index_io; only its commit-side fields are used)
+hipError_t rq_launch_append_check(const rq_append_args &a, const rq_round_args *commit_round, hipStream_t stream);
+hipError_t rq_launch_append_check(const rq_append64_args &a, const rq_round64_args *commit_round, hipStream_t stream);
 
 // commit'[i] = lc[i] > ci[i] ? min(lc[i], last_new[i]) : ci[i]   (raft.go:172-176)
 hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,

@@ -10,8 +10,8 @@ hipError_t rq_launch_round(const rq_round_args &args, uint32_t n, bool joint, in
     return launch_round_impl<int32_t>(args, n, joint, what, variant, stream);
 }
 
-hipError_t rq_launch_append_check(const rq_append_args &a, hipStream_t stream) {
-    return launch_append_check_impl<int32_t>(a, stream);
+hipError_t rq_launch_append_check(const rq_append_args &a, const rq_round_args *commit_round, hipStream_t stream) {
+    return launch_append_check_impl<int32_t>(a, commit_round, stream);
 }
 
 hipError_t rq_launch_follower_clamp(uint64_t count, const int32_t *leader_commit,

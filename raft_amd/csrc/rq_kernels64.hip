@@ -9,8 +9,8 @@ hipError_t rq_launch_round(const rq_round64_args &args, uint32_t n, bool joint, 
     return launch_round_impl<int64_t>(args, n, joint, what, variant, stream);
 }
 
-hipError_t rq_launch_append_check(const rq_append64_args &a, hipStream_t stream) {
-    return launch_append_check_impl<int64_t>(a, stream);
+hipError_t rq_launch_append_check(const rq_append64_args &a, const rq_round64_args *commit_round, hipStream_t stream) {
+    return launch_append_check_impl<int64_t>(a, commit_round, stream);
 }
 
 hipError_t rq_launch_follower_clamp(uint64_t count, const int64_t *leader_commit,

@@ -533,12 +533,14 @@ class DeviceEngine:
         assert b.wide
         return self.round(b, what, variant, want_bits, status)
 
-    def append_check(self, t, G, n, ld, flog_term_bits=0, flog_terms=None, wide=None):
+    def append_check(self, t, G, n, ld, flog_term_bits=0, flog_terms=None, wide=None, commit_round=None):
         """Enqueue the AppendEntries consistency batch on device tensors
         (rq_append_check_dev; int32 or int64 planes).  t: dict of tensors with the C-ABI
         names; active_mask, n_new, match_index, next_index, status, flog_base and
         flog_term_base may be absent; leader_commit + last_new_index + follower_commit
-        (all three or none) add the follower's commit clamp of raft.go:172-176.  follower_term_out may be the follower_term tensor
+        (all three or none) add the follower's commit clamp of raft.go:172-176.
+        commit_round: a RoundDesc of the commit round over the same image (its match is
+        match_index), decided in this launch.  follower_term_out may be the follower_term tensor
         itself (in-place terms); match_index / next_index are updated in place.
         flog_term_bits: entry width of the flog_term tensor (0 = the planes' element)."""
         wide = t["follower_term"].dtype == torch.int64 if wide is None else wide
@@ -561,6 +563,8 @@ class DeviceEngine:
         d.status_out = p("status")
         d.leader_commit, d.last_new_index = p("leader_commit"), p("last_new_index")
         d.follower_commit_io = p("follower_commit")
+        if commit_round is not None:        # a RoundDesc: the leader's commit rule decided in the same launch
+            d.commit_round = C.addressof(commit_round)
         rc = self._l.rq_append_check_dev(self._h, self._stream(), C.byref(d))
         if rc != 0:
             self._check(rc, "rq_append_check_dev")

@@ -1831,3 +1831,141 @@ def test_replication_rounds_stay_on_the_device(dev):
         assert np.array_equal(tb.fetch("status"), exp["status"]) and np.array_equal(
             tb.fetch("success_mask").view(np.uint16), exp["success_mask"]), r
     assert advanced > G // 20 and clamped > G // 5
+
+
+@pytest.mark.parametrize("wide", [False, True])
+@pytest.mark.parametrize("tiled", [False, True])
+def test_replicate_and_commit_in_one_launch(dev, tiled, wide):
+    """rq_append_desc.commit_round: the leader's commit rule decided inside the AppendEntries
+    launch from the matchIndex values it has just produced.  Same results as the batch
+    followed by the commit round (the oracle's append_check, then its commit_advance over the
+    updated matchIndex): n followers + the leader's own slot and n slots alone, masks with
+    inactive slots, narrow / windowed / absent leader-log arenas, in-place commitIndex."""
+    import ctypes as C
+    import torch
+    from raft_amd import _lib
+    from raft_amd.device import TiledAppendBatch, encode_log_terms
+    dt, tdt = (np.int64, torch.int64) if wide else (np.int32, torch.int32)
+    shift = (1 << 40) if wide else 0
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    cases = 0
+    for nf, extra, G, masked, mode in ((4, 1, 30011, False, "narrow"), (4, 0, 4099, True, "plain"),
+                                       (8, 1, 2500, True, "window"), (1, 1, 65, False, "start"),
+                                       (9, 0, 1000, True, "narrow"), (15, 1, 700, False, "plain"),
+                                       (3, 1, 20000, True, "start")):
+        nr = nf + extra
+        b = synth.gen_append(G, nf, seed=50 + nf + G, adversarial=masked)
+        if not masked:
+            del b["active_mask"]
+        c = synth.gen_fused(G, nr, seed=60 + nr)
+        if mode == "start":
+            c = synth.raft_valid(c)
+        if mode == "window":
+            c = synth.window_logs(c, keep_committed=1)
+        # the round's matchIndex array: the batch's follower slots, then (extra) the leader's own
+        match = np.zeros((nr, G), np.int32)
+        match[:nf] = b.match_index[:, :G]
+        if extra:
+            match[nf] = c.match[nf, :G]
+        b["leader_term"] = c.leader_term[:G].copy()
+        kw = dict(n_new=b.n_new, match_index=b.match_index, next_index=b.next_index, G=G)
+        if masked:
+            kw["active_mask"] = b.active_mask
+        exp = o.append_check(b.follower_term, b.leader_term, b.prev_log_index, b.prev_log_term, b.flog_off, b.flog_term, **kw)
+        m2 = match.copy(); m2[:nf] = exp["match_index"][:, :G]
+        ckw = dict(log_base=c.log_base) if mode == "window" else {}
+        exp_c, exp_st = o.commit_advance(m2, c.commit, c.leader_term, c.log_off, c.log_term, G=G, **ckw)
+        # device image
+        wb = synth.Batch(b)
+        if wide:
+            for k in ("follower_term", "leader_term", "prev_log_term", "flog_term"):
+                wb[k] = b[k].astype(np.int64) + shift
+            for k in ("prev_log_index", "n_new", "next_index"):
+                wb[k] = b[k].astype(np.int64)
+        wb["match_index"] = match.astype(dt)                      # nr rows: the batch touches the first nf
+        commit = c.commit[:G].astype(dt)
+        ts, ln = synth.term_start_form(c) if mode == "start" else (None, None)
+        arena, bits, tbase = encode_log_terms((c.log_term.astype(np.int64) + shift).astype(dt), c.log_off,
+                                              0 if mode == "narrow" else (64 if wide else 32), mode == "narrow")
+        log_term = up(arena if arena.size else np.zeros(1, arena.dtype))
+        d = _lib.RoundDesc()
+        d.struct_size = C.sizeof(_lib.RoundDesc)
+        d.layout, d.what, d.G, d.n = (8 if wide else 4), 1, G, nr
+        if tiled:
+            ins = dict(commit=commit)
+            if mode == "start":
+                ins.update(log_term_start=ts.astype(dt), log_len=ln.view(np.int32))
+            else:
+                ins["log_off"] = c.log_off.view(np.int32)
+            if mode == "window":
+                ins["log_base"] = c.log_base[:G].astype(dt)
+            if tbase is not None:
+                ins["log_term_base"] = tbase.astype(dt)
+            # TiledAppendBatch lays match_index out with the batch's n rows: give it the round's rows instead
+            tb = TiledAppendBatch(synth.Batch({**wb, "match_index": wb["match_index"][:nf]}),
+                                  extra_in={**ins, "round_match": match.astype(dt)},
+                                  extra_out=[("round_status", 1, np.uint8)])
+            t = dict(tb.t)
+            t["match_index"] = tb.t["round_match"]
+            d.tile_bytes, d.out_tile_bytes = tb.tile_bytes, tb.out_tile_bytes
+            ptr = lambda k: tb.t[k].data_ptr()
+            fetch = lambda k: tb.fetch(k)
+            G_ld = G
+        else:
+            t = {k: up(wb[k]) for k in ("follower_term", "leader_term", "prev_log_index", "prev_log_term", "n_new",
+                                        "next_index")}
+            t["round_match"] = t["match_index"] = up(match.astype(dt))
+            if masked:
+                t["active_mask"] = up(b.active_mask.view(np.int16))
+            t["flog_off"] = up(b.flog_off.view(np.int32))
+            t["flog_term"] = up(wb["flog_term"] if wb["flog_term"].size else np.zeros(1, dt))
+            t["follower_term_out"] = t["follower_term"]
+            t["success_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
+            t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
+            t["status"] = torch.zeros(G, dtype=torch.uint8, device="cuda:0")
+            t["commit"] = up(commit)
+            t["round_status"] = torch.zeros(G, dtype=torch.uint8, device="cuda:0")
+            if mode == "start":
+                t["log_term_start"], t["log_len"] = up(ts.astype(dt)), up(ln.view(np.int32))
+            else:
+                t["log_off"] = up(c.log_off.view(np.int32))
+            if mode == "window":
+                t["log_base"] = up(c.log_base[:G].astype(dt))
+            if tbase is not None:
+                t["log_term_base"] = up(tbase.astype(dt))
+            d.ld = G
+            ptr = lambda k: t[k].data_ptr()
+            fetch = lambda k: t[k].cpu().numpy()
+            G_ld = G
+        d.match = ptr("round_match")
+        d.commit = d.commit_out = ptr("commit")                          # advanced in place
+        d.status_out = ptr("round_status")
+        if mode == "start":
+            d.log_term_start, d.log_len = ptr("log_term_start"), ptr("log_len")
+        else:
+            d.leader_term, d.log_off, d.log_term = ptr("leader_term"), ptr("log_off"), log_term.data_ptr()
+            d.log_terms, d.log_term_bits = int(c.log_term.size), bits
+            if mode == "window":
+                d.log_base = ptr("log_base")
+            if tbase is not None:
+                d.log_term_base = ptr("log_term_base")
+        if tiled:
+            dev.append_check(t, G, nf, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=wide, commit_round=d)
+        else:
+            dev.append_check(t, G, nf, G_ld, flog_terms=int(b.flog_term.size), wide=wide, commit_round=d)
+        torch.cuda.synchronize()
+        case = (nf, extra, G, masked, mode, tiled, wide)
+        got_match = np.asarray(fetch("round_match")).reshape(nr, -1)[:, :G]
+        assert np.array_equal(got_match, m2), case
+        assert np.array_equal(np.asarray(fetch("commit")).reshape(-1)[:G], exp_c), case
+        assert np.array_equal(np.asarray(fetch("round_status")).reshape(-1)[:G], exp_st), case
+        assert np.array_equal(np.asarray(fetch("success_mask")).reshape(-1)[:G].view(np.uint16), exp["success_mask"][:G]), case
+        assert np.array_equal(np.asarray(fetch("status")).reshape(-1)[:G], exp["status"][:G]), case
+        cases += int((exp_c != c.commit[:G]).sum() > 0)
+    assert cases >= 5
+    # the round must read the batch's own matchIndex array
+    d.match = ptr("commit")
+    t2 = dict(t)
+    with pytest.raises(Exception):
+        dev.append_check(t2, G, nf, G, flog_term_bits=tb.term_bits if tiled else 0,
+                         flog_terms=tb.flog_terms if tiled else int(b.flog_term.size), wide=wide, commit_round=d)
