@@ -1773,8 +1773,10 @@ def test_fuzz_append_batches(dev):
     assert len(seen) == 8
 
 
-def test_replication_rounds_stay_on_the_device(dev):
-    """Four rounds of replicate -> leader commit -> follower commit on ONE tiled image with
+@pytest.mark.parametrize("one_launch", [False, True])
+def test_replication_rounds_stay_on_the_device(dev, one_launch):
+    """(one_launch: the commit round rides in the batch's launch, rq_append_desc.commit_round.)
+    Four rounds of replicate -> leader commit -> follower commit on ONE tiled image with
     nothing but each round's RPC arguments going up: the AppendEntries batch updates matchIndex
     and applies raft.go:172-176 with the leaders' commitIndex array as leaderCommit, the commit
     round advances that same array in place.  Every array after every round against the
@@ -1818,8 +1820,10 @@ def test_replication_rounds_stay_on_the_device(dev):
         li = (pi + nn).astype(np.int32)
         for k, a in (("prev_log_index", pi), ("prev_log_term", pt), ("n_new", nn), ("last_new_index", li)):
             tb.store(k, a)
-        dev.append_check(tb.t, G, n, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=False)
-        assert dev._l.rq_round_dev(dev._h, torch.cuda.current_stream().cuda_stream, C.byref(d)) == 0
+        dev.append_check(tb.t, G, n, G, flog_term_bits=tb.term_bits, flog_terms=tb.flog_terms, wide=False,
+                         commit_round=d if one_launch else None)
+        if not one_launch:
+            assert dev._l.rq_round_dev(dev._h, torch.cuda.current_stream().cuda_stream, C.byref(d)) == 0
         exp = o.append_check(ft, b.leader_term, pi, pt, b.flog_off, b.flog_term, n_new=nn, match_index=mi, next_index=ni)
         fc2 = o.append_commit(exp, lc, li, fc, n_new=nn)
         lc2, st = o.commit_advance(exp["match_index"], lc, b.leader_term, c.log_off, c.log_term)
