@@ -205,12 +205,11 @@ def timed_launches(torch, device, launch, steps, warmup, preheat):
     return e0.elapsed_time(e1) / steps
 
 
-def extras(args, torch, synth, DeviceBatch, eng, device, host_batches):
+def extras(args, torch, synth, DeviceBatch, eng, device, host_batches, out):
     """Secondary figures, each a few hundred launches: the same fused round in the
     wide (int64) layout -- Go's int is 64-bit, raft.go:35-68 --, with the plain
     32-bit log-term arena, and the mixed 3-9 peer + joint-consensus workload."""
     import numpy as np
-    out = {}
     G, n = args.groups, args.peers
     steps, warmup = 120, 12
 
@@ -639,9 +638,17 @@ def main():
         if plain and not args.no_extras:
             del sets
             torch.cuda.empty_cache()
-            line["extra"] = extras(args, torch, synth, DeviceBatch, eng, device, host_batches)
+            # a failure in a secondary figure must not cost the line: what was measured so far stays
+            line["extra"] = {}
+            try:
+                extras(args, torch, synth, DeviceBatch, eng, device, host_batches, line["extra"])
+            except Exception as e:
+                line["extra"]["error"] = "%s: %s" % (type(e).__name__, e)
         if world == 1 and not args.no_cpu_baseline and args.workload == "fused":
-            line["cpu_baseline"] = cpu_baseline(args, synth)
+            try:
+                line["cpu_baseline"] = cpu_baseline(args, synth)
+            except Exception as e:
+                line["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         sys.stdout.flush()
         os.dup2(json_fd, 1)
         print(json.dumps(line), flush=True)
