@@ -144,9 +144,9 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
             if ((uint32_t)p < r.m) mi[p] = __builtin_nontemporal_load(a.match_index_io + append_index<TILED, T>(a.tile_bytes, ld, g, p));
         }
     }
-    // COMMIT: matchIndex of every slot the commit round counts -- what this batch produces
-    // stays in registers, the rest (slots without an RPC; the leader's own slot, read at the
-    // end) was loaded above with the batch's own planes
+    // COMMIT: matchIndex of every slot the commit round counts -- what this batch produces stays
+    // in registers; slots without an RPC were loaded above with the batch's own planes, the
+    // leader's own slot beyond the batch's planes is read at the end
     constexpr int L = NMAX < 16 ? NMAX + 1 : 16;
     T mv[L];
     if constexpr (COMMIT) {
@@ -157,15 +157,15 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
         const bool on = (act >> p) & 1u;
-        const bool r = on && lt >= ft[p];
+        const bool rch = on && lt >= ft[p];
         const bool csr = slice_ok(o0[p], o1[p], a.flog_terms);
         const U wi = window_slot(pi[p], fb[p]);
         const bool in = csr && wi < (U)(o1[p] - o0[p]);
-        reach |= (uint32_t)r << p;
+        reach |= (uint32_t)rch << p;
         inb |= (uint32_t)in << p;
         bad |= (uint32_t)(on && !csr) << p;
         tg[p] = 0;
-        if (r && in)
+        if (rch && in)
             tg[p] = (T)((U)load_term<true, T>(a.flog_term, a.flog_term_bits, (size_t)o0[p] + (size_t)wi) + (U)tbase);
     }
     // pure outputs live in their own tile block; follower terms updated in place stay with the inputs
@@ -176,16 +176,16 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     for (int p = 0; p < NMAX; p++) {
         if (!((act >> p) & 1u)) continue;
         const size_t s = append_index<TILED, T>(a.tile_bytes, ld, g, p);
-        const bool r = (reach >> p) & 1u, in = (inb >> p) & 1u;
-        const bool success = r && in && tg[p] == pt[p];
+        const bool rch = (reach >> p) & 1u, in = (inb >> p) & 1u;
+        const bool success = rch && in && tg[p] == pt[p];
         sd |= (uint32_t)(lt > ft[p]) << p;
         ok |= (uint32_t)success << p;
-        st |= (r && !in) ? kStLogOob : 0;
+        st |= (rch && !in) ? kStLogOob : 0;
         __builtin_nontemporal_store(tmax(ft[p], lt), a.follower_term_out + append_index<TILED, T>(fo_tile, ld, g, p));
         if (upd) {
             T m2 = mi[p], n2 = ni[p];
             if (success) { m2 = (T)((U)pi[p] + (U)nn[p]); n2 = (T)((U)m2 + (U)1); }
-            else if (r) { n2 = n2 > 1 ? n2 - 1 : 1; }
+            else if (rch) { n2 = n2 > 1 ? n2 - 1 : 1; }
             if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
             if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
             if constexpr (COMMIT) { if (a.match_index_io) mv[p] = m2; }
