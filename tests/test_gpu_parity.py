@@ -1852,7 +1852,7 @@ def test_replicate_and_commit_in_one_launch(dev, tiled, wide):
     dt, tdt = (np.int64, torch.int64) if wide else (np.int32, torch.int32)
     shift = (1 << 40) if wide else 0
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
-    cases = 0
+    cases, checked_bad_offsets = 0, False
     for nf, extra, G, masked, mode in ((4, 1, 30011, False, "narrow"), (4, 0, 4099, True, "plain"),
                                        (8, 1, 2500, True, "window"), (1, 1, 65, False, "start"),
                                        (9, 0, 1000, True, "narrow"), (15, 1, 700, False, "plain"),
@@ -1966,7 +1966,23 @@ def test_replicate_and_commit_in_one_launch(dev, tiled, wide):
         assert np.array_equal(np.asarray(fetch("success_mask")).reshape(-1)[:G].view(np.uint16), exp["success_mask"][:G]), case
         assert np.array_equal(np.asarray(fetch("status")).reshape(-1)[:G], exp["status"][:G]), case
         cases += int((exp_c != c.commit[:G]).sum() > 0)
-    assert cases >= 5
+        if not tiled and not wide and nf == 4 and mode == "narrow":
+            # broken leader-log offsets in the fused launch: a status bit, no advance, no stray read
+            off = c.log_off.copy()
+            bad = np.arange(3, G - 1, 7)
+            off[bad] = 0xFFFFFF00
+            t["log_off"].copy_(up(off.view(np.int32)))
+            t["commit"].copy_(up(commit))
+            t["match_index"].copy_(up(match.astype(dt)))
+            dev.append_check(t, G, nf, G_ld, flog_terms=int(b.flog_term.size), wide=wide, commit_round=d)
+            torch.cuda.synchronize()
+            o64 = off.astype(np.int64)
+            okc = (o64[:-1] <= o64[1:]) & (o64[1:] <= int(c.log_term.size))
+            rs = t["round_status"].cpu().numpy()
+            assert (~okc).sum() > 10 and ((rs & 4) != 0).tolist() == (~okc).tolist()
+            assert np.array_equal(t["commit"].cpu().numpy()[~okc], commit[~okc])
+            checked_bad_offsets = True
+    assert cases >= 5 and (checked_bad_offsets or tiled or wide)
     # the round must read the batch's own matchIndex array
     d.match = ptr("commit")
     t2 = dict(t)
