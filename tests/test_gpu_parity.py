@@ -763,18 +763,32 @@ def test_windowed_log_arena(dev, variant):
             assert np.array_equal(db3.results()["commit"], exp2.commit)
 
 
+def _fuzz_seed(default):
+    """RQ_FUZZ_SEED / RQ_FUZZ_ITERS let a soak run (tools/gpu/soak.sh) repeat the fuzz tests with
+    other seeds and many more cases than the suite's fixed ones."""
+    return int(os.environ.get("RQ_FUZZ_SEED", default))
+
+
+def _fuzz_iters(default):
+    return int(os.environ.get("RQ_FUZZ_ITERS", default))
+
+
+def _fuzz_data(seed):
+    return seed + 100003 * int(os.environ.get("RQ_FUZZ_SEED", 0))
+
+
 def test_fuzz_shapes_and_variants(dev):
     """Random group counts, cluster sizes, plane strides and kernel builds."""
     from raft_amd.device import DeviceBatch
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(_fuzz_seed(2024))
     variants = [0, 1, 0x100, 0x101, 0x200, 0x301, 0x400]
-    for it in range(60):
+    for it in range(_fuzz_iters(60)):
         n = int(rng.integers(1, 17))
         G = int(rng.integers(1, 3000))
         ld = G + int(rng.choice([0, 1, 3, 4, 64, 129]))
         variant = int(rng.choice(variants))
         gen = synth.gen_adversarial if it % 2 else synth.gen_fused
-        b = gen(G, n, seed=5000 + it, ld=ld)
+        b = gen(G, n, seed=_fuzz_data(5000 + it), ld=ld)
         exp = o.fused_round(*b.fused_args(), G=G)
         db = DeviceBatch(b)
         dev.fused_round(db, variant=variant)
@@ -786,18 +800,18 @@ def test_fuzz_layouts_windows_and_summaries(dev):
     window, summary width and base, kernel build, group count and stride."""
     import torch
     from raft_amd.device import DeviceBatch, summary_buffer_bytes
-    rng = np.random.default_rng(77)
+    rng = np.random.default_rng(_fuzz_seed(77))
     variants = [0, 1, 0x100, 0x101, 0x200, 0x301, 0x400]
-    for it in range(96):
+    for it in range(_fuzz_iters(96)):
         G = int(rng.integers(1, 2500))
         wide, joint, window = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
         bits = int(rng.choice([0, 4, 8, 16]))
         variant = int(rng.choice(variants))
         if joint:
-            b = synth.gen_mixed(G, seed=900 + it)
+            b = synth.gen_mixed(G, seed=_fuzz_data(900 + it))
             kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
         else:
-            b = synth.gen_fused(G, int(rng.integers(1, 17)), seed=900 + it, ld=G + int(rng.choice([0, 1, 4, 64])))
+            b = synth.gen_fused(G, int(rng.integers(1, 17)), seed=_fuzz_data(900 + it), ld=G + int(rng.choice([0, 1, 4, 64])))
             kw = {}
         if window:
             b = synth.window_logs(b, keep_committed=int(rng.integers(0, 3)))
@@ -1695,10 +1709,10 @@ def test_fuzz_append_batches(dev):
     follower commit rule present or not -- against the oracle on the same batch."""
     import torch
     from raft_amd.device import TiledAppendBatch, encode_log_terms
-    rng = np.random.default_rng(4242)
+    rng = np.random.default_rng(_fuzz_seed(4242))
     up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
     seen = set()
-    for it in range(120):
+    for it in range(_fuzz_iters(120)):
         n, G = int(rng.integers(1, 17)), int(rng.integers(1, 2600))
         tiled, wide = bool(rng.integers(2)), bool(rng.integers(2))
         ld = G if tiled else G + int(rng.choice([0, 1, 5, 64]))
@@ -1706,7 +1720,7 @@ def test_fuzz_append_batches(dev):
         in_place, books, rule = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
         bits = int(rng.choice([0, 8, 16, 32]))
         dt = np.int64 if wide else np.int32
-        b = synth.gen_append(G, n, seed=7000 + it, ld=ld, adversarial=adv)
+        b = synth.gen_append(G, n, seed=_fuzz_data(7000 + it), ld=ld, adversarial=adv)
         if wide:
             for k in ("follower_term", "leader_term", "prev_log_term", "flog_term"):
                 b[k] = b[k].astype(np.int64) + (1 << 40)
