@@ -1768,8 +1768,59 @@ def test_fuzz_append_batches(dev):
             t["success_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
             t["stepdown_mask"] = torch.zeros(G, dtype=torch.int16, device="cuda:0")
             t["status"] = torch.zeros(G, dtype=torch.uint8, device="cuda:0")
-            dev.append_check(t, G, n, ld, flog_term_bits=ebits, flog_terms=int(enc.size), wide=wide)
+            fuse = books and bool(rng.integers(2))         # the leader's commit round in the same launch
+            rd = None
+            if fuse:
+                import ctypes as C
+                from raft_amd import _lib
+                nr = n + (int(rng.integers(2)) if n < 16 else 0)
+                cmode = str(rng.choice(["plain", "narrow", "window", "start"]))
+                c = synth.gen_fused(G, nr, seed=_fuzz_data(9000 + it))
+                if cmode == "start":
+                    c = synth.raft_valid(c)
+                if cmode == "window":
+                    c = synth.window_logs(c, keep_committed=int(rng.integers(0, 3)))
+                rmatch = np.zeros((nr, ld), dt)
+                rmatch[:n] = w.match_index
+                if nr > n:
+                    rmatch[n, :G] = c.match[n, :G]
+                t["match_index"] = up(rmatch)
+                cshift = (1 << 40) if wide else 0
+                t["r_commit"], t["r_status"] = up(c.commit[:G].astype(dt)), torch.zeros(G, dtype=torch.uint8, device="cuda:0")
+                t["r_commit_out"] = torch.zeros_like(t["r_commit"])
+                rd = _lib.RoundDesc()
+                rd.struct_size = C.sizeof(_lib.RoundDesc)
+                rd.layout, rd.what, rd.G, rd.n, rd.ld = (8 if wide else 4), 1, G, nr, ld
+                rd.match, rd.commit = t["match_index"].data_ptr(), t["r_commit"].data_ptr()
+                rd.commit_out, rd.status_out = t["r_commit_out"].data_ptr(), t["r_status"].data_ptr()
+                if cmode == "start":
+                    ts, ln = synth.term_start_form(c)
+                    t["r_ts"], t["r_len"] = up(ts.astype(dt)), up(ln.view(np.int32))
+                    rd.log_term_start, rd.log_len = t["r_ts"].data_ptr(), t["r_len"].data_ptr()
+                else:
+                    arena, abits, tbase = encode_log_terms((c.log_term.astype(np.int64) + cshift).astype(dt), c.log_off,
+                                                           0 if cmode == "narrow" else (64 if wide else 32), cmode == "narrow")
+                    t["r_lt"], t["r_off"] = up((c.leader_term[:G].astype(np.int64) + cshift).astype(dt)), up(c.log_off.view(np.int32))
+                    t["r_arena"] = up(arena if arena.size else np.zeros(1, arena.dtype))
+                    rd.leader_term, rd.log_off, rd.log_term = t["r_lt"].data_ptr(), t["r_off"].data_ptr(), t["r_arena"].data_ptr()
+                    rd.log_terms, rd.log_term_bits = int(c.log_term.size), abits
+                    if tbase is not None:
+                        t["r_tb"] = up(tbase.astype(dt))
+                        rd.log_term_base = t["r_tb"].data_ptr()
+                    if cmode == "window":
+                        t["r_lb"] = up(c.log_base[:G].astype(dt))
+                        rd.log_base = t["r_lb"].data_ptr()
+            dev.append_check(t, G, n, ld, flog_term_bits=ebits, flog_terms=int(enc.size), wide=wide, commit_round=rd)
             torch.cuda.synchronize()
+            if fuse:
+                m2 = rmatch[:, :G].astype(np.int64)
+                m2[:n] = exp["match_index"][:, :G]
+                ckw = dict(log_base=c.log_base) if cmode == "window" else {}
+                exp_c, exp_rs = o.commit_advance(m2.astype(np.int32), c.commit, c.leader_term, c.log_off, c.log_term, G=G, **ckw)
+                assert np.array_equal(t["r_commit_out"].cpu().numpy(), exp_c), (case, nr, cmode)
+                assert np.array_equal(t["r_status"].cpu().numpy(), exp_rs), (case, nr, cmode)
+                assert np.array_equal(t["match_index"].cpu().numpy()[:, :G], m2), (case, nr, cmode)
+                seen.add("fused")
             got = {k: t[k].cpu().numpy() for k in ("success_mask", "stepdown_mask", "status")}
             got["follower_term"] = t["follower_term_out"].cpu().numpy()[:, :G]
             for k in (("match_index", "next_index") if books else ()) + (("follower_commit",) if rule else ()):
@@ -1779,12 +1830,12 @@ def test_fuzz_append_batches(dev):
         assert np.array_equal(got["status"], exp["status"][:G]), case
         assert np.array_equal(got["follower_term"], exp["follower_term"][:, :G]), case
         if books:
-            assert np.array_equal(got["match_index"], exp["match_index"][:, :G]), case
+            assert np.array_equal(got["match_index"][:n], exp["match_index"][:, :G]), case     # (a fused round adds the leader's row)
             assert np.array_equal(got["next_index"], exp["next_index"][:, :G]), case
         if rule:
             assert np.array_equal(got["follower_commit"], exp_fc[:, :G]), case
         seen.add((tiled, wide, rule))
-    assert len(seen) == 8
+    assert len(seen) == 9
 
 
 @pytest.mark.parametrize("one_launch", [False, True])
