@@ -544,6 +544,66 @@ def test_resident_driver_tracks_the_oracle_over_incremental_steps():
 
 
 @pytest.mark.gpu
+def test_resident_driver_random_schedule():
+    """The resident driver under a random schedule (RQ_FUZZ_SEED / RQ_FUZZ_ITERS: seed and number
+    of steps, for soak runs): a group count that does not fill its last tile, every step a random
+    number of groups touched -- logs growing a little, a lot (moves inside the arena, now and then
+    a full re-layout), matchIndex redrawn, candidate terms raised -- and after every step the
+    objects where the oracle's round over a fresh flatten of all objects puts them."""
+    import os
+    G, n = 3001, 5
+    seed = int(os.environ.get("RQ_FUZZ_SEED", 5))
+    steps = int(os.environ.get("RQ_FUZZ_ITERS", 8))
+    c, b = _build(G, n, seed=100 + seed)
+    rng = np.random.default_rng(seed)
+    rebuilt = 0
+    try:
+        c.use_resident(0)
+        for g in range(G):
+            c.roles(g, *c.get_roles(g))
+        for it in range(steps):
+            if it:
+                touched = rng.choice(G, int(rng.integers(0, 400)), replace=False)
+                for g in touched.tolist():
+                    lead, cand = c.get_roles(g)
+                    if lead >= 0:
+                        s = c.get(g, lead)
+                        u = rng.random()
+                        grow = int(rng.integers(0, 3)) if u < 0.9 else int(rng.integers(20, 60)) if u < 0.995 else 20000
+                        ln = s["logLen"] + grow
+                        terms = [1 + (i * int(s["currentTerm"])) // ln for i in range(ln)]
+                        c.seed(g, lead, s["currentTerm"], s["votedFor"], h.LEADER, s["commitIndex"], terms)
+                        c.set_match(g, lead, [int(x) for x in rng.integers(0, ln, n)])
+                    if cand >= 0:
+                        s = c.get(g, cand)
+                        c.seed(g, cand, s["currentTerm"] + int(rng.integers(0, 2)), s["votedFor"], h.CANDIDATE, s["commitIndex"])
+            rc, f = c.flatten(log_cap=1 << 24)
+            assert rc == 0
+            exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                                f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
+            roles_before = [c.get_roles(g) for g in range(G)]
+            rc, rep = c.step_resident()
+            assert rc == 0, it
+            rebuilt += int(rep["rebuilt"])
+            moved = (exp.commit != f["commit"]) | (exp.stepdown_mask != 0) | (exp.elected != 0) | (exp.status != 0)
+            assert rep["changed"] == int(moved.sum()), it
+            for g in range(G):
+                lead, cand = roles_before[g]
+                if cand >= 0:
+                    for p in range(n):
+                        assert c.get(g, p)["currentTerm"] == exp.voter_term[p, g], (it, g, p)
+                    assert (c.get_roles(g)[0] == cand) == bool(exp.elected[g]), (it, g)
+                if lead >= 0:
+                    assert c.get(g, lead)["commitIndex"] == exp.commit[g], (it, g)
+            for g in range(G):
+                lead, cand = c.get_roles(g)
+                c.l.rh_group_roles(c.h, g, lead, cand)
+        assert rebuilt >= 1
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 def test_resident_driver_without_a_log_arena():
     """All leaders' logs have Raft's own shape (terms never decrease, none above the
     leader's term): the resident image holds no log arena, only the index where each
