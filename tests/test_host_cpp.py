@@ -569,7 +569,7 @@ def test_resident_driver_random_schedule():
                     if lead >= 0:
                         s = c.get(g, lead)
                         u = rng.random()
-                        grow = int(rng.integers(0, 3)) if u < 0.9 else int(rng.integers(20, 60)) if u < 0.995 else 20000
+                        grow = int(rng.integers(0, 3)) if u < 0.9 else int(rng.integers(20, 60)) if u < 0.999 else 5000
                         ln = s["logLen"] + grow
                         terms = [1 + (i * int(s["currentTerm"])) // ln for i in range(ln)]
                         c.seed(g, lead, s["currentTerm"], s["votedFor"], h.LEADER, s["commitIndex"], terms)
@@ -577,8 +577,8 @@ def test_resident_driver_random_schedule():
                     if cand >= 0:
                         s = c.get(g, cand)
                         c.seed(g, cand, s["currentTerm"] + int(rng.integers(0, 2)), s["votedFor"], h.CANDIDATE, s["commitIndex"])
-            rc, f = c.flatten(log_cap=1 << 24)
-            assert rc == 0
+            rc, f = c.flatten(log_cap=1 << 25)
+            assert rc == 0, (it, "the test's own flat image is too small")
             exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
                                 f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
             roles_before = [c.get_roles(g) for g in range(G)]
