@@ -209,6 +209,45 @@ for label, n_planes, use_mask, term_bits, window, commit_rule in (
     del dab
     torch.cuda.empty_cache()
 
+# replicate -> commit: the batch + the commit round over its matchIndex array (4 followers + the
+# leader's own slot), as two launches and as one (rq_append_desc.commit_round)
+import ctypes as C
+from raft_amd import _lib
+dab = append_sets(4, False, 0, False)
+for s_, t in enumerate(dab):
+    c = synth.gen_fused(G, 5, seed=300 + s_)
+    arena, cbits, _ = encode_log_terms(c.log_term, bits=0)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    t["match_index"] = torch.cat([t["match_index"], up(c.match[4:5, :G])])
+    t["leader_term"] = up(c.leader_term[:G])
+    t["commit"], t["commit_out"] = up(c.commit[:G]), torch.zeros(G, dtype=torch.int32, device=dev)
+    t["log_off"], t["log_term"] = up(c.log_off.view(np.int32)), up(arena)
+    t["round_status"] = torch.zeros(G, dtype=torch.uint8, device=dev)
+    d = _lib.RoundDesc()
+    d.struct_size = C.sizeof(_lib.RoundDesc)
+    d.layout, d.what, d.G, d.n, d.ld = 4, 1, G, 5, G
+    d.match, d.commit, d.leader_term = t["match_index"].data_ptr(), t["commit"].data_ptr(), t["leader_term"].data_ptr()
+    d.log_off, d.log_term, d.log_terms, d.log_term_bits = t["log_off"].data_ptr(), t["log_term"].data_ptr(), int(arena.size), cbits
+    d.commit_out, d.status_out = t["commit_out"].data_ptr(), t["round_status"].data_ptr()
+    t["_round"] = d
+
+
+def two_launches(i):
+    t = dab[i % len(dab)]
+    eng.append_check(t, G, 4, G, flog_term_bits=t["_bits"], flog_terms=t["_terms"])
+    assert eng._l.rq_round_dev(eng._h, torch.cuda.current_stream().cuda_stream, C.byref(t["_round"])) == 0
+
+
+REPL_ALG = APPEND_ALG + 4 * 5 + 20
+out.append(rate("replicate + commit, 1M groups x (4 followers + leader): AppendEntries batch, then the commit round (two launches)",
+                G, REPL_ALG, timed(two_launches, 200, 20)))
+out.append(rate("replicate + commit, 1M groups x (4 followers + leader): one launch (rq_append_desc.commit_round); bytes as for two",
+                G, REPL_ALG, timed(lambda i: eng.append_check(dab[i % len(dab)], G, 4, G, flog_term_bits=dab[i % len(dab)]["_bits"],
+                                                              flog_terms=dab[i % len(dab)]["_terms"],
+                                                              commit_round=dab[i % len(dab)]["_round"]), 200, 20)))
+del dab
+torch.cuda.empty_cache()
+
 path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "configs.json")
 os.makedirs(os.path.dirname(path), exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
