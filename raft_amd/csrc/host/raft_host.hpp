@@ -194,8 +194,9 @@ private:
 // rq_round_desc.tile_bytes (the layout the round kernels run fastest on; the
 // single-group calls address it like planes).  Staging lives in page-locked
 // memory allocated once.
-// Compact (int32) layout; values beyond it make Rebuild fail with RQ_E_RANGE and
-// the caller falls back to BatchedDriver.
+// Compact (int32) layout while every value fits it; a value beyond int32 (Go's int
+// is 64-bit, raft.go:35-68) makes the next Step lay the image out afresh in the wide
+// (int64) layout, where it stays.
 class ResidentDriver {
 public:
     struct Report {
@@ -216,19 +217,23 @@ public:
     // log_term_start).  A log that loses the shape (the reference appends whatever it is
     // sent, raft.go:158-170) makes the next Step lay the image out afresh with an arena.
     bool WithoutArena() const;
+    bool Wide() const { return wide_; }      // the image holds int64 elements
     std::vector<Group> &Groups() { return groups_; }
 
 private:
     struct Impl;
-    int Rebuild();
     struct LogShape {
         bool shaped = true;      // terms never decrease and none exceeds the leader's term
-        int32_t term_start = 0;  // index of the first entry of the leader's term, or the log's length
+        int64_t term_start = 0;  // index of the first entry of the leader's term, or the log's length
         uint32_t len = 0;
     };
-    int FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms, LogShape *shape = nullptr) const;
+    // written once over the element type of the image (int32_t or int64_t)
+    template <typename T> int RebuildT();
+    template <typename T> int StepT(Report *report);
+    template <typename T> int FlattenRow(uint32_t g, T *row, std::vector<T> &terms, LogShape *shape = nullptr) const;
+    template <typename T> void ApplyRow(uint32_t g, const T *row, uint64_t flags);
     LogShape ShapeOf(uint32_t g) const;
-    void ApplyRow(uint32_t g, const int32_t *row, uint64_t flags);
+    bool wide_ = false;
     std::vector<Group> groups_;
     uint32_t slots_;
     int device_;

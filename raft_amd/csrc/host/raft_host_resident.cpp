@@ -13,11 +13,20 @@ namespace {
 
 constexpr uint32_t kMaxRowsPerTransfer = 1u << 18;   // staging rows; more dirty groups than this: full rebuild
 
-bool narrow32(int64_t v, int32_t &out) {
-    if (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX) return false;   // INT32_MIN is the empty-log marker
+// The lowest value of each layout is its empty-log marker and cannot be a value.
+bool narrow(int64_t v, int32_t &out) {
+    if (v <= (int64_t)INT32_MIN || v > (int64_t)INT32_MAX) return false;
     out = (int32_t)v;
     return true;
 }
+bool narrow(int64_t v, int64_t &out) {
+    if (v == INT64_MIN) return false;
+    out = v;
+    return true;
+}
+template <typename T> struct limits;
+template <> struct limits<int32_t> { static constexpr int32_t kMax = INT32_MAX, kBelowAll = INT32_MIN + 1, kLogEmpty = RQ_LOG_EMPTY; };
+template <> struct limits<int64_t> { static constexpr int64_t kMax = INT64_MAX, kBelowAll = INT64_MIN + 1, kLogEmpty = RQ_LOG_EMPTY64; };
 
 // room a group's arena slice keeps for its log to grow before the image is rebuilt
 uint32_t slice_capacity(size_t len) { return (uint32_t)(len + (len / 4 > 4 ? len / 4 : 4)); }
@@ -94,7 +103,7 @@ ResidentDriver::LogShape ResidentDriver::ShapeOf(uint32_t g) const {
         if (start == log.size() && log[i].TermNum == l->currentTerm) start = i;
     }
     if (!log.empty() && log.back().TermNum > l->currentTerm) s.shaped = false;
-    s.term_start = (int32_t)start;
+    s.term_start = (int64_t)start;
     return s;
 }
 
@@ -102,41 +111,44 @@ bool ResidentDriver::WithoutArena() const { return impl_ && impl_->plan && impl_
 
 // `shape` non-null: the image keeps no arena -- the log is only measured (ShapeOf), its
 // terms are not copied and `terms` stays empty.
-int ResidentDriver::FlattenRow(uint32_t g, int32_t *row, std::vector<int32_t> &terms, LogShape *shape) const {
+template <typename T>
+int ResidentDriver::FlattenRow(uint32_t g, T *row, std::vector<T> &terms, LogShape *shape) const {
     const Group &grp = groups_[g];
     const uint32_t n = slots_, k = (uint32_t)grp.Members.size();
     if (k < 1 || k > n || n > RQ_MAX_SLOTS) return RQ_E_ARG;
-    int32_t *match = row, *vt = row + n, *vf = row + 2 * n, *ll = row + 3 * n, *tail = row + 4 * n;
-    for (uint32_t p = 0; p < n; p++) { match[p] = 0; vt[p] = 0; vf[p] = -1; ll[p] = RQ_LOG_EMPTY; }
-    tail[0] = INT32_MAX; tail[1] = 0; tail[2] = INT32_MIN + 1; tail[3] = -1; tail[4] = 0;
+    T *match = row, *vt = row + n, *vf = row + 2 * n, *ll = row + 3 * n, *tail = row + 4 * n;
+    for (uint32_t p = 0; p < n; p++) { match[p] = 0; vt[p] = 0; vf[p] = -1; ll[p] = limits<T>::kLogEmpty; }
+    tail[0] = limits<T>::kMax; tail[1] = 0; tail[2] = limits<T>::kBelowAll; tail[3] = -1; tail[4] = 0; tail[6] = 0;
     const uint32_t mask = (1u << k) - 1u;
-    tail[5] = (int32_t)(mask | (mask << 16));
+    tail[5] = (T)(mask | (mask << 16));
     terms.clear();
     if (const Node *l = grp.Leader) {
-        if (!narrow32(l->commitIndex, tail[0]) || !narrow32(l->currentTerm, tail[1])) return RQ_E_RANGE;
+        if (!narrow(l->commitIndex, tail[0]) || !narrow(l->currentTerm, tail[1])) return RQ_E_RANGE;
         for (uint32_t p = 0; p < k && p < l->matchIndex.size(); p++)
-            if (!narrow32(l->matchIndex[p], match[p])) return RQ_E_RANGE;
+            if (!narrow(l->matchIndex[p], match[p])) return RQ_E_RANGE;
         if (!shape) {
             terms.resize(l->log.size());
             for (size_t i = 0; i < l->log.size(); i++)
-                if (!narrow32(l->log[i].TermNum, terms[i])) return RQ_E_RANGE;
+                if (!narrow(l->log[i].TermNum, terms[i])) return RQ_E_RANGE;
         }
     }
     if (shape) *shape = ShapeOf(g);
     if (const Node *c = grp.Candidate) {
-        if (!narrow32(c->currentTerm, tail[2]) || !narrow32(c->id, tail[3])) return RQ_E_RANGE;
+        if (!narrow(c->currentTerm, tail[2]) || !narrow(c->id, tail[3])) return RQ_E_RANGE;
     }
     for (uint32_t p = 0; p < k; p++) {
         const Node *m = grp.Members[p];
-        if (!narrow32(m->currentTerm, vt[p]) || !narrow32(m->votedFor, vf[p])) return RQ_E_RANGE;
-        if (!m->log.empty() && !narrow32(m->log.back().TermNum, ll[p])) return RQ_E_RANGE;
+        if (!narrow(m->currentTerm, vt[p]) || !narrow(m->votedFor, vf[p])) return RQ_E_RANGE;
+        if (!m->log.empty() && !narrow(m->log.back().TermNum, ll[p])) return RQ_E_RANGE;
     }
     return RQ_OK;
 }
 
 // The whole image: every group flattened, arena slices sized with room to grow,
 // device buffers, staging and the prepared launch made afresh.
-int ResidentDriver::Rebuild() {
+template <typename T>
+int ResidentDriver::RebuildT() {
+    constexpr uint64_t E = sizeof(T);
     const uint32_t G = (uint32_t)groups_.size(), n = slots_;
     if (G == 0 || n < 1 || n > RQ_MAX_SLOTS) return RQ_E_ARG;
     if (!impl_) impl_ = new Impl();
@@ -151,30 +163,34 @@ int ResidentDriver::Rebuild() {
     // The image lives in the 64-group tiles of rq_round_desc.tile_bytes: one block for the
     // inputs (and the state updated in place), one for the pure outputs.  Field offsets
     // inside a tile, widest elements first:
-    const uint64_t slot4 = (uint64_t)n * 256;                    // n slots x 64 groups x 4 bytes
-    const uint64_t o_match = 0, o_vt = slot4, o_vf = 2 * slot4, o_ll = 3 * slot4;
-    const uint64_t o_commit = 4 * slot4, o_lterm = o_commit + 256, o_cterm = o_lterm + 256, o_cid = o_cterm + 256;
-    const uint64_t o_len = o_cid + 256, o_aux = o_len + 256;      // aux: log_off, or log_term_start without an arena
-    const uint64_t o_om = o_aux + 256, o_nm = o_om + 128;
+    const uint64_t row_t = 64 * E, slots_t = (uint64_t)n * row_t;   // one row / n rows of 64 elements
+    const uint64_t o_match = 0, o_vt = slots_t, o_vf = 2 * slots_t, o_ll = 3 * slots_t;
+    const uint64_t o_commit = 4 * slots_t, o_lterm = o_commit + row_t, o_cterm = o_lterm + row_t, o_cid = o_cterm + row_t;
+    const uint64_t o_tstart = o_cid + row_t;                       // log_term_start (element type), unused with an arena
+    const uint64_t o_len = o_tstart + row_t, o_off = o_len + 256;   // 32-bit: log_len, log_off
+    const uint64_t o_om = o_off + 256, o_nm = o_om + 128;
     const uint64_t tile_bytes = o_nm + 128;
-    const uint64_t oo_max = 0, oo_grant = 256, oo_step = 384, oo_elected = 512, oo_status = 576;
-    const uint64_t out_tile_bytes = 768;
+    const uint64_t oo_max = 0, oo_grant = row_t, oo_step = oo_grant + 128, oo_elected = oo_step + 128, oo_status = oo_elected + 64;
+    const uint64_t out_tile_bytes = oo_status + 64 + 64;            // padded to a multiple of 8
     const uint64_t ntiles = ((uint64_t)G + 1 + 63) / 64;         // log_off has G + 1 entries
     std::vector<unsigned char> block(ntiles * tile_bytes, 0);
-    auto w32 = [&](uint64_t off, uint32_t p, uint32_t g) -> int32_t & {
-        return *reinterpret_cast<int32_t *>(block.data() + (uint64_t)(g >> 6) * tile_bytes + off +
-                                            ((uint64_t)p * 64 + (g & 63u)) * 4);
+    auto wT = [&](uint64_t off, uint32_t p, uint32_t g) -> T & {
+        return *reinterpret_cast<T *>(block.data() + (uint64_t)(g >> 6) * tile_bytes + off +
+                                      ((uint64_t)p * 64 + (g & 63u)) * E);
+    };
+    auto w32 = [&](uint64_t off, uint32_t g) -> uint32_t & {
+        return *reinterpret_cast<uint32_t *>(block.data() + (uint64_t)(g >> 6) * tile_bytes + off + (uint64_t)(g & 63u) * 4);
     };
     auto w16 = [&](uint64_t off, uint32_t g) -> uint16_t & {
         return *reinterpret_cast<uint16_t *>(block.data() + (uint64_t)(g >> 6) * tile_bytes + off + (uint64_t)(g & 63u) * 2);
     };
-    std::vector<int32_t> arena;
+    std::vector<T> arena;
     std::vector<uint32_t> len(G);
     I.off.assign((size_t)G + 1, 0);
     I.cap.assign(G, 0);
     mixed_ = false;
     // Do all the leaders' logs have Raft's own shape?  Then the device needs no arena.
-    std::vector<int32_t> tstart(G);
+    std::vector<int64_t> tstart(G);
     std::atomic<bool> all_shaped{true};
     ParallelOverGroups(G, [&](uint32_t g0, uint32_t g1, uint32_t) {
         for (uint32_t g = g0; g < g1; g++) {
@@ -197,33 +213,32 @@ int ResidentDriver::Rebuild() {
     std::atomic<int> err{RQ_OK};
     std::atomic<bool> mixed{false};
     ParallelOverGroups(G, [&](uint32_t g0, uint32_t g1, uint32_t) {
-        std::vector<int32_t> row(words), terms;
+        std::vector<T> row(words), terms;
         for (uint32_t g = g0; g < g1; g++) {
             LogShape shape;
-            int rc = FlattenRow(g, row.data(), terms, I.by_start ? &shape : nullptr);
+            int rc = FlattenRow<T>(g, row.data(), terms, I.by_start ? &shape : nullptr);
             if (rc == RQ_OK && !I.by_start && terms.size() > I.cap[g]) rc = RQ_E_ARG;
+            if (rc == RQ_OK && I.by_start && !narrow(tstart[g], wT(o_tstart, 0, g))) rc = RQ_E_RANGE;
             if (rc != RQ_OK) { err.store(rc); return; }
             for (uint32_t p = 0; p < n; p++) {
-                w32(o_match, p, g) = row[p]; w32(o_vt, p, g) = row[n + p];
-                w32(o_vf, p, g) = row[2 * n + p]; w32(o_ll, p, g) = row[3 * n + p];
+                wT(o_match, p, g) = row[p]; wT(o_vt, p, g) = row[n + p];
+                wT(o_vf, p, g) = row[2 * n + p]; wT(o_ll, p, g) = row[3 * n + p];
             }
-            const int32_t *tail = row.data() + 4 * n;
-            w32(o_commit, 0, g) = tail[0]; w32(o_lterm, 0, g) = tail[1];
-            w32(o_cterm, 0, g) = tail[2]; w32(o_cid, 0, g) = tail[3];
+            const T *tail = row.data() + 4 * n;
+            wT(o_commit, 0, g) = tail[0]; wT(o_lterm, 0, g) = tail[1];
+            wT(o_cterm, 0, g) = tail[2]; wT(o_cid, 0, g) = tail[3];
             w16(o_om, g) = (uint16_t)((uint32_t)tail[5] & 0xFFFFu); w16(o_nm, g) = (uint16_t)((uint32_t)tail[5] >> 16);
             if (groups_[g].Members.size() != n) mixed.store(true);
-            if (I.by_start) {
-                w32(o_aux, 0, g) = tstart[g];
-            } else {
+            if (!I.by_start) {
                 len[g] = (uint32_t)terms.size();
-                std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * 4);
-                w32(o_aux, 0, g) = (int32_t)I.off[g];
+                std::memcpy(arena.data() + I.off[g], terms.data(), terms.size() * E);
+                w32(o_off, g) = I.off[g];
             }
-            w32(o_len, 0, g) = (int32_t)len[g];
+            w32(o_len, g) = len[g];
         }
     });
     if (err.load() != RQ_OK) return err.load();
-    if (!I.by_start) w32(o_aux, 0, G) = (int32_t)I.off[G];
+    if (!I.by_start) w32(o_off, G) = I.off[G];
     mixed_ = mixed.load();
     // free space behind the slices: logs that outgrow their slice move there
     I.tail = arena.size();
@@ -234,7 +249,7 @@ int ResidentDriver::Rebuild() {
 
     rq_round_desc &d = I.desc;
     std::memset(&d, 0, sizeof d);
-    d.struct_size = sizeof d; d.layout = RQ_LAYOUT_I32; d.what = RQ_ROUND_COMMIT | RQ_ROUND_VOTE;
+    d.struct_size = sizeof d; d.layout = E == 8 ? RQ_LAYOUT_I64 : RQ_LAYOUT_I32; d.what = RQ_ROUND_COMMIT | RQ_ROUND_VOTE;
     d.G = G; d.n = n; d.ld = G; d.log_terms = arena.size();
     d.tile_bytes = tile_bytes; d.out_tile_bytes = out_tile_bytes;
 #define RH_TRY(x) do { int rh_rc_ = (x); if (rh_rc_ != RQ_OK) return rh_rc_; } while (0)
@@ -247,13 +262,13 @@ int ResidentDriver::Rebuild() {
     d.commit = in_dev + o_commit; d.cand_term = in_dev + o_cterm; d.cand_id = in_dev + o_cid;
     d.log_len = (const uint32_t *)(in_dev + o_len);
     if (I.by_start) {
-        d.log_term_start = in_dev + o_aux;
+        d.log_term_start = in_dev + o_tstart;
     } else {
         d.leader_term = in_dev + o_lterm;
-        d.log_off = (const uint32_t *)(in_dev + o_aux);
+        d.log_off = (const uint32_t *)(in_dev + o_off);
         void *arena_dev = nullptr;
-        RH_TRY(I.dalloc((uint64_t)arena.size() * 4, &arena_dev));
-        RH_TRY(rq_copy_to_device(I.e, arena_dev, arena.data(), (uint64_t)arena.size() * 4));
+        RH_TRY(I.dalloc((uint64_t)arena.size() * E, &arena_dev));
+        RH_TRY(rq_copy_to_device(I.e, arena_dev, arena.data(), (uint64_t)arena.size() * E));
         d.log_term = arena_dev;
     }
     if (mixed_) {
@@ -276,7 +291,8 @@ int ResidentDriver::Rebuild() {
     const uint64_t nrows = I.row_cap;
     I.term_cap = 64ull * nrows < I.arena_entries ? 64ull * nrows : I.arena_entries;
     if (I.by_start) I.term_cap = 0;                  // rows carry no terms
-    const uint64_t in_bytes = (nrows * (words + 2) + 1 + I.term_cap) * 4, out_bytes = nrows * (8 + (n + 2) * 4);
+    // going up: group ids and term offsets (32-bit), then rows and terms (element type, 8-byte aligned)
+    const uint64_t in_bytes = (nrows * 2 + 2) * 4 + (nrows * words + I.term_cap) * E, out_bytes = nrows * (8 + (n + 2) * E);
     RH_TRY(I.dalloc(in_bytes, (void **)&I.d_in));    RH_TRY(I.halloc(in_bytes, &I.h_in));
     RH_TRY(I.dalloc(out_bytes, (void **)&I.d_out));  RH_TRY(I.halloc(out_bytes, &I.h_out));
     RH_TRY(I.halloc(bit_words * 8, &I.h_cbits));
@@ -287,7 +303,8 @@ int ResidentDriver::Rebuild() {
 
 // One gathered row back into the objects: voters' terms and roles
 // (raft.go:219-221), the leader's commitIndex, BecomeLeader for a winner.
-void ResidentDriver::ApplyRow(uint32_t g, const int32_t *row, uint64_t flags) {
+template <typename T>
+void ResidentDriver::ApplyRow(uint32_t g, const T *row, uint64_t flags) {
     Group &grp = groups_[g];
     const uint32_t stepdown = (uint32_t)(flags >> 16) & 0xFFFFu;
     const bool elected = ((flags >> 32) & 0xFFu) != 0;
@@ -311,6 +328,19 @@ void ResidentDriver::ApplyRow(uint32_t g, const int32_t *row, uint64_t flags) {
 }
 
 int ResidentDriver::Step(Report *report) {
+    // the compact layout until a value does not fit it; the wide one from then on
+    if (!wide_) {
+        const int rc = StepT<int32_t>(report);
+        if (rc != RQ_E_RANGE) return rc;
+        wide_ = true;
+        if (impl_) { impl_->release(); }          // no prepared launch: the next step lays the image out afresh
+    }
+    return StepT<int64_t>(report);
+}
+
+template <typename T>
+int ResidentDriver::StepT(Report *report) {
+    constexpr uint64_t E = sizeof(T);
     Report rep;
     flagged_.clear();
     bool need_rebuild = impl_ == nullptr || impl_->plan == nullptr;
@@ -321,19 +351,19 @@ int ResidentDriver::Step(Report *report) {
         const size_t words = 4 * (size_t)n + 7;
         // block going up, packed for r rows: group ids | term offsets (r + 1) | rows | terms
         uint32_t *gids = (uint32_t *)I.h_in, *roff = gids + r;
-        int32_t *rows = (int32_t *)(roff + r + 1), *rterms = rows + (size_t)r * words;
-        std::vector<int32_t> terms;
+        T *rows = (T *)(I.h_in + (((uint64_t)r * 2 + 1) * 4 + 7) / 8 * 8), *rterms = rows + (size_t)r * words;
+        std::vector<T> terms;
         uint64_t used = 0;
         for (uint32_t i = 0; i < r && !need_rebuild; i++) {
             const uint32_t g = dirty_[i];
-            int32_t *row = rows + (size_t)i * words;
+            T *row = rows + (size_t)i * words;
             LogShape shape;
-            RH_TRY(FlattenRow(g, row, terms, I.by_start ? &shape : nullptr));
+            RH_TRY(FlattenRow<T>(g, row, terms, I.by_start ? &shape : nullptr));
             if (!mixed_ && groups_[g].Members.size() != n) { need_rebuild = true; break; }
             if (I.by_start) {
                 // a log that lost Raft's shape needs the arena back: everything is laid out afresh
                 if (!shape.shaped) { need_rebuild = true; break; }
-                row[4 * n + 6] = shape.term_start;
+                if (!narrow(shape.term_start, row[4 * n + 6])) return RQ_E_RANGE;
                 gids[i] = g;
                 roff[i] = (uint32_t)used;            // lengths only: no terms travel
                 used += shape.len;
@@ -350,15 +380,15 @@ int ResidentDriver::Step(Report *report) {
                 I.tail += want;
             }
             if (used + terms.size() > I.term_cap) { need_rebuild = true; break; }
-            row[4 * n + 6] = (int32_t)I.off[g];
+            row[4 * n + 6] = (T)I.off[g];
             gids[i] = g;
             roff[i] = (uint32_t)used;
-            std::memcpy(rterms + used, terms.data(), terms.size() * 4);
+            std::memcpy(rterms + used, terms.data(), terms.size() * E);
             used += terms.size();
         }
         if (!need_rebuild) {
             roff[r] = (uint32_t)used;
-            const uint64_t bytes = ((uint64_t)r * (words + 2) + 1 + (I.by_start ? 0 : used)) * 4;
+            const uint64_t bytes = (uint64_t)((const char *)rterms - I.h_in) + (I.by_start ? 0 : used) * E;
             RH_TRY(rq_copy_to_device(I.e, I.d_in, I.h_in, bytes));
             const char *d = I.d_in;
             RH_TRY(rq_groups_scatter_dev(I.e, nullptr, &I.desc, r, (const uint32_t *)d,
@@ -370,7 +400,7 @@ int ResidentDriver::Step(Report *report) {
         }
     }
     if (need_rebuild) {
-        RH_TRY(Rebuild());
+        RH_TRY(RebuildT<T>());
         rep.rebuilt = true;
         rep.uploaded = (uint32_t)groups_.size();
     }
@@ -387,10 +417,10 @@ int ResidentDriver::Step(Report *report) {
         RH_TRY(rq_copy_to_device(I.e, I.d_in, I.h_in, (uint64_t)r * 4));
         RH_TRY(rq_groups_gather_dev(I.e, nullptr, &I.desc, r, (const uint32_t *)I.d_in, I.d_out + (uint64_t)r * 8,
                                     (uint64_t *)I.d_out));
-        RH_TRY(rq_copy_from_device(I.e, I.h_out, I.d_out, (uint64_t)r * (8 + (I.n + 2) * 4)));
+        RH_TRY(rq_copy_from_device(I.e, I.h_out, I.d_out, (uint64_t)r * (8 + (I.n + 2) * E)));
         const uint64_t *flags = (const uint64_t *)I.h_out;
-        const int32_t *orows = (const int32_t *)(I.h_out + (uint64_t)r * 8);
-        for (uint32_t i = 0; i < r; i++) ApplyRow(gids[i], orows + (size_t)i * (I.n + 2), flags[i]);
+        const T *orows = (const T *)(I.h_out + (uint64_t)r * 8);
+        for (uint32_t i = 0; i < r; i++) ApplyRow<T>(gids[i], orows + (size_t)i * (I.n + 2), flags[i]);
         rep.changed += r;
         r = 0;
         return RQ_OK;

@@ -58,6 +58,7 @@ def lib():
         l.rh_resident_mark_dirty.argtypes = [C.c_void_p, C.c_uint32]; l.rh_resident_mark_dirty.restype = None
         l.rh_resident_step.argtypes = [C.c_void_p, u32p]
         l.rh_resident_without_arena.argtypes = [C.c_void_p]
+        l.rh_resident_wide.argtypes = [C.c_void_p]
         l.rh_resident_flagged.argtypes = [C.c_void_p, u32p, u8p, C.c_uint32]
         l.rh_resident_flagged.restype = C.c_uint32
         _l = l
@@ -104,6 +105,10 @@ class Cluster:
     def without_arena(self):
         """True while the resident image keeps no log arena (log_term_start + log_len)."""
         return bool(self.l.rh_resident_without_arena(self.h))
+
+    def resident_wide(self):
+        """True once the resident image holds int64 elements (some value did not fit int32)."""
+        return bool(self.l.rh_resident_wide(self.h))
 
     def flagged(self):
         """(group, status) pairs of the last step: conditions that are Go panics in the reference."""

@@ -544,8 +544,10 @@ def test_resident_driver_tracks_the_oracle_over_incremental_steps():
 
 
 @pytest.mark.gpu
-def test_resident_driver_random_schedule():
-    """The resident driver under a random schedule (RQ_FUZZ_SEED / RQ_FUZZ_ITERS: seed and number
+@pytest.mark.parametrize("wide", [False, True])
+def test_resident_driver_random_schedule(wide):
+    """(wide: every term beyond 2^40, so the image is laid out in int64 elements from the first step.)
+    The resident driver under a random schedule (RQ_FUZZ_SEED / RQ_FUZZ_ITERS: seed and number
     of steps, for soak runs): a group count that does not fill its last tile, every step a random
     number of groups touched -- logs growing a little, a lot (moves inside the arena, now and then
     a full re-layout), matchIndex redrawn, candidate terms raised -- and after every step the
@@ -554,7 +556,8 @@ def test_resident_driver_random_schedule():
     G, n = 3001, 5
     seed = int(os.environ.get("RQ_FUZZ_SEED", 5))
     steps = int(os.environ.get("RQ_FUZZ_ITERS", 8))
-    c, b = _build(G, n, seed=100 + seed)
+    SH = (1 << 40) if wide else 0
+    c, b = _build(G, n, seed=100 + seed, term_shift=SH)
     rng = np.random.default_rng(seed)
     rebuilt = 0
     try:
@@ -571,19 +574,26 @@ def test_resident_driver_random_schedule():
                         u = rng.random()
                         grow = int(rng.integers(0, 3)) if u < 0.9 else int(rng.integers(20, 60)) if u < 0.999 else 5000
                         ln = s["logLen"] + grow
-                        terms = [1 + (i * int(s["currentTerm"])) // ln for i in range(ln)]
+                        terms = [SH + 1 + (i * int(s["currentTerm"] - SH)) // ln for i in range(ln)]
                         c.seed(g, lead, s["currentTerm"], s["votedFor"], h.LEADER, s["commitIndex"], terms)
                         c.set_match(g, lead, [int(x) for x in rng.integers(0, ln, n)])
                     if cand >= 0:
                         s = c.get(g, cand)
                         c.seed(g, cand, s["currentTerm"] + int(rng.integers(0, 2)), s["votedFor"], h.CANDIDATE, s["commitIndex"])
-            rc, f = c.flatten(log_cap=1 << 25)
-            assert rc == 0, (it, "the test's own flat image is too small")
-            exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+            if wide:
+                rc, f = c.flatten64(log_cap=1 << 25)
+                assert rc == 0, (it, "the test's own flat image is too small")
+                exp = o.round64(3, f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
                                 f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
+            else:
+                rc, f = c.flatten(log_cap=1 << 25)
+                assert rc == 0, (it, "the test's own flat image is too small")
+                exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                                    f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
             roles_before = [c.get_roles(g) for g in range(G)]
             rc, rep = c.step_resident()
             assert rc == 0, it
+            assert c.resident_wide() == wide
             rebuilt += int(rep["rebuilt"])
             moved = (exp.commit != f["commit"]) | (exp.stepdown_mask != 0) | (exp.elected != 0) | (exp.status != 0)
             assert rep["changed"] == int(moved.sum()), it
@@ -599,6 +609,57 @@ def test_resident_driver_random_schedule():
                 lead, cand = c.get_roles(g)
                 c.l.rh_group_roles(c.h, g, lead, cand)
         assert rebuilt >= 1
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
+def test_resident_driver_switches_to_the_wide_layout():
+    """A resident image in the compact layout meets its first value beyond int32 (one candidate's
+    term, Go's int is 64-bit): that step lays the image out afresh in int64 elements and decides
+    like the wide oracle; later steps stay wide and move only touched rows again."""
+    G, n = 1500, 5
+    c, b = _build(G, n, seed=77)
+    try:
+        c.use_resident(0)
+        for g in range(G):
+            c.roles(g, *c.get_roles(g))
+        rc, rep = c.step_resident()
+        assert rc == 0 and rep["rebuilt"] and not c.resident_wide()
+        for g in range(G):                                          # the batched driver's roles (used by flatten) in step
+            c.l.rh_group_roles(c.h, g, *c.get_roles(g))
+        g_big = next(g for g in range(G) if c.get_roles(g)[1] >= 0)
+        for it in range(2):
+            if it == 0:
+                cand = c.get_roles(g_big)[1]
+                s = c.get(g_big, cand)
+                c.seed(g_big, cand, (1 << 40) + 5, s["votedFor"], h.CANDIDATE, s["commitIndex"])
+            else:
+                for g in (3, 4, 5):
+                    lead = c.get_roles(g)[0]
+                    if lead >= 0:
+                        c.set_match(g, lead, [1] * n)
+            rc, f = c.flatten64(log_cap=1 << 22)
+            assert rc == 0
+            exp = o.round64(3, f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                            f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
+            roles_before = [c.get_roles(g) for g in range(G)]
+            rc, rep = c.step_resident()
+            assert rc == 0 and c.resident_wide()
+            assert rep["rebuilt"] == (it == 0)
+            for g in range(G):
+                lead, cand = roles_before[g]
+                if cand >= 0:
+                    for p in range(n):
+                        assert c.get(g, p)["currentTerm"] == exp.voter_term[p, g], (it, g, p)
+                    assert (c.get_roles(g)[0] == cand) == bool(exp.elected[g]), (it, g)
+                if lead >= 0:
+                    assert c.get(g, lead)["commitIndex"] == exp.commit[g], (it, g)
+            for g in range(G):
+                lead, cand = c.get_roles(g)
+                c.l.rh_group_roles(c.h, g, lead, cand)
+        # every voter of that group saw the huge term
+        assert all(c.get(g_big, p)["currentTerm"] == (1 << 40) + 5 for p in range(n))
     finally:
         c.close()
 
