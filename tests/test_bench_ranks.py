@@ -46,3 +46,23 @@ def test_launcher_never_imports_torch_in_the_parent():
     assert "import torch" not in head
     body = src[src.index("def main():"):]
     assert body.index("launch_ranks(args)") < body.index("import torch")
+
+
+@pytest.mark.gpu
+def test_bench_single_rank_line_carries_every_secondary_figure():
+    """The default (one-rank) line at a small group count: one JSON line with the roofline
+    object and every secondary figure under `extra`, none of them failed."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--groups", "65536", "--steps", "8", "--warmup", "2",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=400, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 1 and r["steps"] == 8 and r["value"] > 0 and r["dtype"] == "int32"
+    assert r["roofline"]["bound"] == "hbm" and 0 < r["roofline"]["frac"] < 1 and r["roofline"]["kernel_ms"] > 0
+    assert "error" not in r["extra"], r["extra"].get("error")
+    for k in ("arena_i32", "three_streams", "term_start", "planes", "commit_only", "vote_only", "append_check",
+              "append_check_commit", "replicate_commit", "i64", "i64_narrow_arena", "mixed", "mixed_term_start"):
+        assert k in r["extra"], k
+        assert r["extra"][k].get("kernel_ms", r["extra"][k].get("ms_per_round", 0)) > 0, k
