@@ -8,6 +8,9 @@
  *   rq_cli host      rq_fused_round on host buffers
  *   rq_cli device    rq_device_alloc + rq_copy_to_device + rq_round_dev on
  *                    the default stream + rq_stream_sync + rq_copy_from_device
+ *   rq_cli replicate one AppendEntries batch through rq_append_check_dev with the
+ *                    follower commit rule and the leader's commit round in the same
+ *                    launch (its own input format, see replicate())
  *
  * Input (whitespace separated integers):
  *   G n
@@ -54,7 +57,100 @@ static int to_device(rq_engine *e, const void *src, size_t bytes, void **out) {
     return rq_copy_to_device(e, *out, src, bytes);
 }
 
+/* Input: G nf extra, then
+ *   follower_term[nf][G] leader_term[G] prev_log_index[nf][G] prev_log_term[nf][G] n_new[nf][G]
+ *   flog_off[nf*G+1] flog_term[flog_off[nf*G]]
+ *   match[nf+extra][G] next_index[nf][G] follower_commit[nf][G] last_new_index[nf][G]
+ *   commit[G] log_off[G+1] log_term[log_off[G]]
+ * (nf follower slots, extra = 1 if the leader's own slot follows them in match; the leaders'
+ * commit array is the RPCs' leaderCommit and is advanced in place by the commit round).
+ * Output, one line each: follower_term (nf lines), success_mask, stepdown_mask, status,
+ * match (nf + extra lines), next_index (nf), follower_commit (nf), commit, round status. */
+static int replicate(void) {
+    rq_engine *e = NULL;
+    long long G_in, nf_in, extra_in;
+    if (scanf("%lld %lld %lld", &G_in, &nf_in, &extra_in) != 3 || G_in < 1 || nf_in < 1 || extra_in < 0 || extra_in > 1 ||
+        nf_in + extra_in > RQ_MAX_SLOTS) {
+        fprintf(stderr, "rq_cli: bad header\n");
+        return 2;
+    }
+    const uint32_t G = (uint32_t)G_in, nf = (uint32_t)nf_in, nr = nf + (uint32_t)extra_in;
+    const size_t fp = (size_t)nf * G, rp = (size_t)nr * G;
+    int32_t *ft = read_i32(fp), *lt = read_i32(G), *pi = read_i32(fp), *pt = read_i32(fp), *nn = read_i32(fp);
+    uint32_t *foff = (uint32_t *)read_i32(fp + 1);
+    const size_t farena = foff[fp];
+    int32_t *fterm = read_i32(farena);
+    int32_t *match = read_i32(rp), *next = read_i32(fp), *fc = read_i32(fp), *li = read_i32(fp);
+    int32_t *commit = read_i32(G);
+    uint32_t *log_off = (uint32_t *)read_i32((size_t)G + 1);
+    const size_t arena = log_off[G];
+    int32_t *log_term = read_i32(arena);
+    uint16_t *ok = (uint16_t *)calloc(G, 2), *sd = (uint16_t *)calloc(G, 2);
+    uint8_t *st = (uint8_t *)calloc(G, 1), *rst = (uint8_t *)calloc(G, 1);
+
+    CHECK(rq_engine_create(0, 64, 1, 64, &e));          /* binds the device; every buffer below is ours */
+    void *d_ft, *d_lt, *d_pi, *d_pt, *d_nn, *d_foff, *d_fterm, *d_match, *d_next, *d_fc, *d_li, *d_commit, *d_off, *d_log;
+    void *d_ok, *d_sd, *d_st, *d_rst;
+    CHECK(to_device(e, ft, fp * 4, &d_ft));       CHECK(to_device(e, lt, (size_t)G * 4, &d_lt));
+    CHECK(to_device(e, pi, fp * 4, &d_pi));       CHECK(to_device(e, pt, fp * 4, &d_pt));
+    CHECK(to_device(e, nn, fp * 4, &d_nn));       CHECK(to_device(e, foff, (fp + 1) * 4, &d_foff));
+    CHECK(to_device(e, fterm, farena * 4, &d_fterm));
+    CHECK(to_device(e, match, rp * 4, &d_match)); CHECK(to_device(e, next, fp * 4, &d_next));
+    CHECK(to_device(e, fc, fp * 4, &d_fc));       CHECK(to_device(e, li, fp * 4, &d_li));
+    CHECK(to_device(e, commit, (size_t)G * 4, &d_commit));
+    CHECK(to_device(e, log_off, ((size_t)G + 1) * 4, &d_off));
+    CHECK(to_device(e, log_term, arena * 4, &d_log));
+    CHECK(to_device(e, ok, (size_t)G * 2, &d_ok)); CHECK(to_device(e, sd, (size_t)G * 2, &d_sd));
+    CHECK(to_device(e, st, G, &d_st));             CHECK(to_device(e, rst, G, &d_rst));
+
+    rq_round_desc r;                                    /* the commit round that would follow the batch */
+    memset(&r, 0, sizeof r);
+    r.struct_size = sizeof r; r.layout = RQ_LAYOUT_I32; r.what = RQ_ROUND_COMMIT;
+    r.G = G; r.n = nr; r.ld = G;
+    r.match = d_match;                                  /* the array the batch updates */
+    r.commit = d_commit; r.commit_out = d_commit;       /* advanced in place */
+    r.leader_term = d_lt; r.log_off = (const uint32_t *)d_off; r.log_term = d_log; r.log_terms = arena;
+    r.status_out = (uint8_t *)d_rst;
+    rq_append_desc a;
+    memset(&a, 0, sizeof a);
+    a.struct_size = sizeof a; a.layout = RQ_LAYOUT_I32;
+    a.G = G; a.n = nf; a.ld = G; a.flog_terms = farena;
+    a.follower_term = d_ft; a.leader_term = d_lt; a.prev_log_index = d_pi; a.prev_log_term = d_pt; a.n_new = d_nn;
+    a.flog_off = (const uint32_t *)d_foff; a.flog_term = d_fterm;
+    a.follower_term_out = d_ft;                         /* terms in place */
+    a.success_mask = (uint16_t *)d_ok; a.stepdown_mask = (uint16_t *)d_sd; a.status_out = (uint8_t *)d_st;
+    a.match_index_io = d_match; a.next_index_io = d_next;
+    a.leader_commit = d_commit; a.last_new_index = d_li; a.follower_commit_io = d_fc;
+    a.commit_round = &r;
+    CHECK(rq_append_check_dev(e, NULL, &a));
+    CHECK(rq_stream_sync(e, NULL));
+    CHECK(rq_copy_from_device(e, ft, d_ft, fp * 4));       CHECK(rq_copy_from_device(e, ok, d_ok, (size_t)G * 2));
+    CHECK(rq_copy_from_device(e, sd, d_sd, (size_t)G * 2)); CHECK(rq_copy_from_device(e, st, d_st, G));
+    CHECK(rq_copy_from_device(e, match, d_match, rp * 4)); CHECK(rq_copy_from_device(e, next, d_next, fp * 4));
+    CHECK(rq_copy_from_device(e, fc, d_fc, fp * 4));       CHECK(rq_copy_from_device(e, commit, d_commit, (size_t)G * 4));
+    CHECK(rq_copy_from_device(e, rst, d_rst, G));
+    void *all[] = {d_ft, d_lt, d_pi, d_pt, d_nn, d_foff, d_fterm, d_match, d_next, d_fc, d_li, d_commit, d_off, d_log,
+                   d_ok, d_sd, d_st, d_rst};
+    for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) CHECK(rq_device_free(e, all[i]));
+    for (uint32_t p = 0; p < nf; p++) print_i32(ft + (size_t)p * G, G);
+    for (uint32_t g = 0; g < G; g++) printf(g ? " %u" : "%u", ok[g]);
+    printf("\n");
+    for (uint32_t g = 0; g < G; g++) printf(g ? " %u" : "%u", sd[g]);
+    printf("\n");
+    for (uint32_t g = 0; g < G; g++) printf(g ? " %u" : "%u", st[g]);
+    printf("\n");
+    for (uint32_t p = 0; p < nr; p++) print_i32(match + (size_t)p * G, G);
+    for (uint32_t p = 0; p < nf; p++) print_i32(next + (size_t)p * G, G);
+    for (uint32_t p = 0; p < nf; p++) print_i32(fc + (size_t)p * G, G);
+    print_i32(commit, G);
+    for (uint32_t g = 0; g < G; g++) printf(g ? " %u" : "%u", rst[g]);
+    printf("\n");
+    CHECK(rq_engine_destroy(e));
+    return 0;
+}
+
 int main(int argc, char **argv) {
+    if (argc > 1 && strcmp(argv[1], "replicate") == 0) return replicate();
     const int device_mode = argc > 1 && strcmp(argv[1], "device") == 0;
     rq_engine *e = NULL;
     long long G_in, n_in;

@@ -86,3 +86,40 @@ def test_plain_c_benchmark_runs():
         shares.append(p.stderr.split("elected")[1].split("%")[0])
     assert shares[0] == shares[1]                              # identical decisions
     assert 10 < float(shares[0]) < 90                          # a plausible share of the groups elects
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [0, 1])
+def test_cli_replicate_round_from_plain_c(extra):
+    """`rq_cli replicate`: one AppendEntries batch with the follower commit rule and the
+    leader's commit round in the same launch, the two descriptors (one pointing at the other)
+    filled in by a C program -- against the oracle's append_check, append_commit and
+    commit_advance run in that order."""
+    G, nf = 2003, 4
+    nr = nf + extra
+    b = synth.with_follower_commit(synth.gen_append(G, nf, seed=31 + extra), seed=2)
+    c = synth.gen_fused(G, nr, seed=32 + extra)
+    match = np.concatenate([b.match_index, c.match[nf:nr]]).astype(np.int32)
+    b["leader_term"] = c.leader_term[:G].copy()
+    parts = ["%d %d %d" % (G, nf, extra)]
+    for a in (b.follower_term, b.leader_term, b.prev_log_index, b.prev_log_term, b.n_new, b.flog_off, b.flog_term,
+              match, b.next_index, b.follower_commit, b.last_new_index, c.commit[:G], c.log_off, c.log_term):
+        parts.append(" ".join(str(int(x)) for x in np.asarray(a).ravel()))
+    p = subprocess.run([CLI, "replicate"], input="\n".join(parts) + "\n", capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    rows = [np.array(line.split(), dtype=np.int64) for line in p.stdout.strip().split("\n")]
+    assert len(rows) == nf + 3 + nr + nf + nf + 2
+    it = iter(rows)
+    take = lambda k: np.stack([next(it) for _ in range(k)])
+    ft, ok, sd, st = take(nf), next(it), next(it), next(it)
+    m, ni, fc, commit, rst = take(nr), take(nf), take(nf), next(it), next(it)
+    exp = o.append_check(b.follower_term, b.leader_term, b.prev_log_index, b.prev_log_term, b.flog_off, b.flog_term,
+                         n_new=b.n_new, match_index=b.match_index, next_index=b.next_index)
+    exp_fc = o.append_commit(exp, c.commit[:G], b.last_new_index, b.follower_commit, n_new=b.n_new)
+    m2 = match.copy(); m2[:nf] = exp["match_index"]
+    exp_c, exp_rst = o.commit_advance(m2, c.commit, c.leader_term, c.log_off, c.log_term)
+    assert np.array_equal(ft, exp["follower_term"]) and np.array_equal(ok, exp["success_mask"])
+    assert np.array_equal(sd, exp["stepdown_mask"]) and np.array_equal(st, exp["status"])
+    assert np.array_equal(m, m2) and np.array_equal(ni, exp["next_index"]) and np.array_equal(fc, exp_fc)
+    assert np.array_equal(commit, exp_c) and np.array_equal(rst, exp_rst)
+    assert (exp_c != c.commit[:G]).any() and (exp_fc != b.follower_commit).any()
