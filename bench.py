@@ -121,7 +121,7 @@ def parse():
                     help="keep every array as a slot-major plane field[p * ld + g] instead of the default 64-group "
                          "tiles (rq_round_desc.tile_bytes: one input and one output stream per wave)")
     ap.add_argument("--layout", choices=["i32", "i64"], default="i32",
-                    help="i64: the wide layout (rq_round64_dev), values shifted beyond the int32 range")
+                    help="i64: the wide layout (RQ_LAYOUT_I64 descriptors), values shifted beyond the int32 range")
     ap.add_argument("--no-bits", action="store_true", help="skip the packed elected-bit summary output")
     ap.add_argument("--no-status", action="store_true", help="skip the per-group status byte output")
     ap.add_argument("--cpu-seconds", type=float, default=8.0, help="CPU work per baseline leg")
@@ -184,6 +184,65 @@ def cpu_baseline(args, synth):
                        "C restatement of raft.go (Go toolchain absent)" % (
                            G, args.peers, out["multi"]["passes"], out["multi"]["seconds"]),
                 single_thread_value=out["single"]["value"], host_cpus=os.cpu_count())
+
+
+def verify_against_oracle(db, hb, what=3, want_bits=True, status=True):
+    """Proof that the timed launches computed the right thing: the outputs DeviceBatch db holds
+    after the timed region (every launch rewrites them from constant inputs) against the CPU
+    oracle's decisions for the same host batch hb (raft.go:181-223 per voter slot, :151 for the
+    looked-up term), bit for bit on every group.  The oracle is the checker here, never the
+    thing timed.  Returns the `verified` object of the JSON line."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as o
+    G = db.G
+    res = db.results()
+    kw = dict(G=G)
+    if "old_mask" in hb:
+        kw.update(old_mask=hb["old_mask"], new_mask=hb["new_mask"])
+    if "log_base" in hb:
+        kw["log_base"] = hb["log_base"]
+    commit_in = (hb["match"], hb["commit"], hb["leader_term"], hb["log_off"], hb["log_term"])
+    vote_in = (hb["voter_term"], hb["voted_for"], hb["last_log_term"], hb["cand_term"], hb["cand_id"])
+    if db.wide:
+        names = ("match", "commit", "leader_term", "log_off", "log_term", "voter_term", "voted_for",
+                 "last_log_term", "cand_term", "cand_id")
+        exp = o.round64(what, **{k: hb[k] for k in names[:5] if what & 1}, **{k: hb[k] for k in names[5:] if what & 2}, **kw)
+    elif what == 3:
+        exp = o.fused_round(*commit_in, *vote_in, **kw)
+    elif what == 1:
+        c, st = o.commit_advance(*commit_in, **kw)
+        exp = dict(commit=c, status=st)
+    else:
+        kw.pop("log_base", None)
+        exp = o.vote_tally(*vote_in, **kw)
+    bad, checked = [], []
+
+    def same(name, got, want):
+        checked.append(name)
+        if not np.array_equal(got, want):
+            bad.append(name)
+
+    if what & 1:
+        same("commit", res["commit"], exp["commit"][:G])
+    if what & 2:
+        for f in ("grant_mask", "stepdown_mask", "elected", "max_term"):
+            same(f, res[f], exp[f][:G])
+        gv, ev = res["voter_term"][:, :G], exp["voter_term"][:, :G]
+        if "old_mask" in hb:                    # slots outside both configurations are not evaluated
+            mem = (hb["old_mask"] | hb["new_mask"]).astype(np.int64)
+            mm = ((mem[None, :G] >> np.arange(gv.shape[0])[:, None]) & 1).astype(bool)
+            gv, ev = gv[mm], ev[mm]
+        same("voter_term", gv, ev)
+        if want_bits:
+            bits = np.unpackbits(res["elected_bits"].view(np.uint8), bitorder="little")
+            same("elected_bits", bits[:G], exp["elected"][:G])
+    if status:
+        same("status", res["status"], exp["status"][:G])
+    return {"vs": "oracle", "groups": G, "ok": not bad, "outputs_checked": checked, "mismatched": bad,
+            "layout": "%s, %s, %d-bit log-term arena entries" % (
+                "int64" if db.wide else "int32", "64-group tiles" if db.tile_bytes else "slot-major planes",
+                db.log_term_bits) + (", log_term_start" if db.term_start else "")}
 
 
 def timed_launches(torch, device, launch, steps, warmup, preheat):
@@ -358,7 +417,8 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches, out):
     ms = timed_launches(torch, device, lambda i: eng.fused_round(wide[i % S]), steps, warmup, S)
     out["i64"] = dict(kernel_ms=ms, frac=frac(alg_bytes_per_group(n, "fused", "i64"), ms), input_sets=S,
                       alg_bytes_per_group=alg_bytes_per_group(n, "fused", "i64"),
-                      note="rq_round64_dev, terms and ids shifted beyond 2^41, int64 arena entries")
+                      note="wide layout (RQ_LAYOUT_I64), terms and ids shifted beyond 2^41, int64 arena entries",
+                      verified=verify_against_oracle(wide[0], whost[0]))
     del wide
     torch.cuda.empty_cache()
     # the same with the arena as a host would keep it: entries as narrow as the differences from each
@@ -392,7 +452,8 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches, out):
     ms = timed_launches(torch, device, lambda i: eng.fused_round(msets[i % S]), steps, warmup, S)
     out["mixed"] = dict(kernel_ms=ms, frac=frac(bpg, ms), input_sets=S, alg_bytes_per_group=bpg,
                         mean_member_slots=members,
-                        note="mixed 3-9 peers + 10% joint consensus, Zipf(1.2) logs up to 4096 entries")
+                        note="mixed 3-9 peers + 10% joint consensus, Zipf(1.2) logs up to 4096 entries",
+                        verified=verify_against_oracle(msets[0], first))
     del msets
     torch.cuda.empty_cache()
     # the same workload without the log arena (log_term_start): a looked-up term costs a
@@ -469,7 +530,7 @@ def main():
 
     # one run-long counter of groups whose commit offset left the 16-bit summary window
     escape_counter = torch.zeros(2, dtype=torch.int32, device=device) if ex is not None else None
-    sets, first_mixed, host_batches = [], None, []
+    sets, first_mixed, host_batches, verify_host = [], None, [], None
     for s in range(S):
         seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
         if args.workload == "fused":
@@ -487,6 +548,8 @@ def main():
                                term_shift=1 << 41, id_shift=1 << 42, seed=seed)
         elif args.workload == "fused":
             host_batches.append(b)
+        if s == 0:
+            verify_host = b                  # what set 0's outputs are checked against after the timed region
         kw = {}
         if args.workload == "mixed" and sets:
             kw["share_log_with"] = sets[0]
@@ -584,6 +647,18 @@ def main():
         dist.all_gather(ids, torch.tensor([dev_index], dtype=torch.int64, device=device))
         devices = [int(t.item()) for t in ids]
 
+    # outside the timed region: set 0's outputs, as the timed launches left them, against the oracle
+    what_bits = {"fused": 3, "commit": 1, "vote": 2}[args.what]
+    verified = verify_against_oracle(sets[0], verify_host, what=what_bits,
+                                     want_bits=not args.no_bits and args.what != "commit",
+                                     status=not args.no_status or args.what != "fused")
+    if use_dist:            # every rank checks its own shard; the line carries the AND
+        okt = torch.tensor([1 if verified["ok"] else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        verified["ok"] = bool(okt.item())
+        verified["groups"] = verified["groups"] * world
+    failed = not verified["ok"]
+
     summary_escapes = None
     if ex is not None:      # the 16-bit window must have held on this rank for the whole run
         summary_escapes = int(escape_counter[0].item())
@@ -633,6 +708,7 @@ def main():
                          "host_enqueue_ms_per_step": (t_enqueued - t0) / args.steps * 1e3,
                          "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else "rq_round_joint<16,...>"},
             "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
+            "verified": verified,
         }
         plain = world == 1 and args.workload == "fused" and args.layout == "i32" and args.what == "fused"
         if plain and not args.no_extras:
@@ -644,6 +720,8 @@ def main():
                 extras(args, torch, synth, DeviceBatch, eng, device, host_batches, line["extra"])
             except Exception as e:
                 line["extra"]["error"] = "%s: %s" % (type(e).__name__, e)
+            failed = failed or any(isinstance(v, dict) and v.get("verified", {}).get("ok") is False
+                                   for v in line["extra"].values())
         if world == 1 and not args.no_cpu_baseline and args.workload == "fused":
             try:
                 line["cpu_baseline"] = cpu_baseline(args, synth)
@@ -658,6 +736,9 @@ def main():
         ex.close()
     if use_dist:
         dist.destroy_process_group()
+    if failed:
+        sys.stderr.write("bench.py: outputs of the timed launches differ from the oracle: %s\n" % verified)
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -1,11 +1,13 @@
 """rq_fused_round_noalloc -- the host-buffer fused round staged through a fixed
-array inside the library's device image -- against rq_fused_round on the same
-inputs, bit for bit, through the C-ABI."""
+array inside the library's device image -- through the C-ABI, bit for bit against
+the CPU oracle (the checker) and against rq_fused_round (the entry point it is a
+variant of) on the same inputs."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
+import oracle_lib as o
 from raft_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -37,7 +39,13 @@ def _same(out, ref, G):
         assert np.array_equal(out[f], getattr(ref, f)), f
 
 
-def test_noalloc_round_equals_the_engine_round(engine):
+def _check(out, engine, b):
+    """First the oracle (what decides right and wrong), then the engine's own entry point."""
+    _same(out, o.fused_round(*b.fused_args(), G=b.G), b.G)
+    _same(out, engine.fused_round(*b.fused_args(), G=b.G), b.G)
+
+
+def test_noalloc_round_equals_the_oracle_and_the_engine_round(engine):
     """Two calls in a row, the second smaller (it must not see the first one's
     data), then an adversarial batch, a padded stride and other cluster sizes."""
     from raft_amd import _lib
@@ -48,8 +56,7 @@ def test_noalloc_round_equals_the_engine_round(engine):
     for b in cases:
         rc, out = _noalloc(l, b)
         assert rc == 0, rc
-        ref = engine.fused_round(*b.fused_args(), G=b.G)
-        _same(out, ref, b.G)
+        _check(out, engine, b)
 
 
 def test_noalloc_round_limits_and_errors(engine):
@@ -65,10 +72,10 @@ def test_noalloc_round_limits_and_errors(engine):
     assert _noalloc(l, b, device=99)[0] in (-1, -4)           # no such device
     rc, out = _noalloc(l, b)                                  # still works after the refusals
     assert rc == 0
-    _same(out, engine.fused_round(*b.fused_args(), G=b.G), b.G)
+    _check(out, engine, b)
     # on a caller's stream
     import torch
     s = torch.cuda.Stream()
     rc, out = _noalloc(l, b, stream=s.cuda_stream)
     assert rc == 0
-    _same(out, engine.fused_round(*b.fused_args(), G=b.G), b.G)
+    _check(out, engine, b)
