@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define RQ_VERSION 0x000204 /* 0.2.4: rq_append_desc gained the follower commit clamp (leader_commit, last_new_index, follower_commit_io) and commit_round */
+#define RQ_VERSION 0x000300 /* 0.3.0: rq_round_desc gained the segment table (n_segments, seg_first_group, seg_n); 0.2.x descriptors are still accepted */
 
 /* return codes */
 #define RQ_OK            0
@@ -320,10 +320,33 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  *   variant     kernel build: 0 = library default; RQ_VARIANT_PLAIN = default
  *               cache policy instead of non-temporal streaming; bits 8-11 =
  *               threads per block / 64 (1..4).  Never changes results.
+ *   n_segments / seg_first_group / seg_n   a host that keeps groups of DIFFERENT
+ *               cluster sizes in one image of n planes orders them by size and
+ *               says so here: the groups seg_first_group[s] .. seg_first_group[s+1]
+ *               - 1 all have the fixed cluster size seg_n[s] (1..9, at most n: their
+ *               members are the seg_n[s] lowest slots and, if the round has member
+ *               masks, old == new == (1 << seg_n[s]) - 1 -- the caller vouches for
+ *               it, the masks of these groups are not read), or, with seg_n[s] == 0,
+ *               are decided through their member masks (joint consensus, tiles in
+ *               which sizes meet; with NULL masks: all n slots).  1 .. RQ_MAX_SEGMENTS
+ *               segments covering [0, G) in order, seg_first_group[0] = 0,
+ *               seg_first_group[n_segments] = G, every boundary between two
+ *               segments a multiple of 64.  Still ONE launch: each block runs the
+ *               fixed-size code of its segment, so the nine groups in ten of a
+ *               mixed deployment that are plain clusters are decided at the speed
+ *               of the fixed-size round and only the rest pays for masks.  The table
+ *               never changes a result for groups it describes truthfully (a group
+ *               listed under the wrong size is decided as a cluster of that size;
+ *               nothing is read out of bounds).  old_mask / new_mask may be NULL
+ *               when no group is in joint consensus.
  * Output planes may alias the matching input plane (commit_out = commit,
- * voter_term_out = voter_term: state updated in place between rounds). */
+ * voter_term_out = voter_term: state updated in place between rounds).
+ * A struct_size of RQ_ROUND_DESC_SIZE_V2 (the descriptor up to log_term_start, as
+ * built against 0.2.x headers) is accepted and means "no segment table". */
 #define RQ_LAYOUT_I32 4
 #define RQ_LAYOUT_I64 8
+#define RQ_MAX_SEGMENTS 16
+#define RQ_ROUND_DESC_SIZE_V2 ((uint32_t)offsetof(struct rq_round_desc, n_segments))
 #define RQ_LOG_EMPTY64  INT64_MIN
 #define RQ_ROUND_COMMIT 1
 #define RQ_ROUND_VOTE   2
@@ -362,6 +385,10 @@ typedef struct rq_round_desc {
     uint32_t *summary_escapes;
     uint64_t *start_signal;     /* may be NULL (see rq_stream_wait_signal) */
     const void *log_term_start; /* may be NULL (see above) */
+    /* segment table, see above; n_segments = 0: none */
+    uint32_t n_segments;
+    uint32_t seg_first_group[RQ_MAX_SEGMENTS + 1];
+    uint8_t  seg_n[RQ_MAX_SEGMENTS];
 } rq_round_desc;
 
 int rq_round_dev(rq_engine *e, void *stream, const rq_round_desc *d);
@@ -374,6 +401,20 @@ int rq_round_dev(rq_engine *e, void *stream, const rq_round_desc *d);
  * capture. */
 typedef struct rq_plan rq_plan;
 int rq_plan_round(rq_engine *e, const rq_round_desc *d, rq_plan **out);
+/* Several rounds in ONE launch.  descs[0 .. count) (1 .. RQ_MAX_SEGMENTS descriptors of
+ * one struct_size, layout, `what` and block size; no RQ_VARIANT_PLAIN, no segment
+ * tables; start_signal only in descs[0]) name independent images, each with its own
+ * arrays, cluster size or member masks, tiling and log arena; rq_plan_launch decides all
+ * of them with one grid, every block running the fixed-size or the member-mask code of its
+ * image.  Two uses.  A deployment whose groups have DIFFERENT cluster sizes keeps one
+ * image per size, each in its own compact 64-group tiles (a tile of a 3-peer image holds
+ * 3 slots, not the 9 or 16 of the widest group), plus one image with member masks for the
+ * groups in joint consensus: measured at 1M groups of 3-9 peers this is the fastest way
+ * to decide a mixed population.  And a host with several short batches amortises the
+ * ramp-up and drain of a launch over all of them.  The argument structs are copied
+ * to device memory here (the plan owns 300 bytes per image); results are those of
+ * `count` separate rq_plan_launch calls.  No counterpart in the reference. */
+int rq_plan_rounds(rq_engine *e, const rq_round_desc *descs, uint32_t count, rq_plan **out);
 /* Start signal (rq_round_desc.start_signal).  A second stream that consumes the
  * outputs of the rounds enqueued so far -- the summary all-gather of a sharded
  * deployment -- would normally wait for an event recorded behind the last of

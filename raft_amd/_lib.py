@@ -36,7 +36,8 @@ class RoundDesc(C.Structure):
                 ("elected", vp), ("max_term", vp), ("status_out", vp), ("elected_bits", vp),
                 ("changed_bits", vp),
                 ("commit_summary", vp), ("summary_base", vp), ("summary_escapes", vp),
-                ("start_signal", vp), ("log_term_start", vp)]
+                ("start_signal", vp), ("log_term_start", vp),
+                ("n_segments", u32), ("seg_first_group", u32 * 17), ("seg_n", C.c_uint8 * 16)]
 
 
 class AppendDesc(C.Structure):
@@ -81,6 +82,7 @@ PROTOTYPES = {
     # device-pointer launches: descriptors of raw addresses so torch data_ptr() ints pass through
     "rq_round_dev": [vp, vp, C.POINTER(RoundDesc)],
     "rq_plan_round": [vp, C.POINTER(RoundDesc), C.POINTER(vp)],
+    "rq_plan_rounds": [vp, C.POINTER(RoundDesc), u32, C.POINTER(vp)],
     "rq_groups_scatter_dev": [vp, vp, C.POINTER(RoundDesc), u32, vp, vp, vp, vp, vp],
     "rq_groups_gather_dev": [vp, vp, C.POINTER(RoundDesc), u32, vp, vp, vp],
     # wide layout on host buffers: what, G, m, ld, then 2 masks + 11 inputs + 7 outputs

@@ -6,6 +6,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -19,6 +20,15 @@ struct rq_plan {
     int what;
     rq_round_args args;
     rq_round64_args args64;
+    bool segmented;     // segs is a checked table
+    rq_round_segs segs;
+    // rq_plan_rounds: `images` rounds decided by one grid.  The argument structs of all
+    // images live in host memory (many) and, the same bytes, in device memory (table).
+    uint32_t images;    // 0: a single round (the fields above)
+    void *many;         // rq_round_args[images] or rq_round64_args[images]
+    void *table;        // device copy
+    uint32_t image_n[RQ_MAX_SEGS];
+    bool image_joint[RQ_MAX_SEGS];
 };
 
 struct rq_engine {
@@ -343,11 +353,47 @@ int round_args_from_desc(const rq_round_desc &d, rq_round_args_t<T> &a) {
     return RQ_OK;
 }
 
-int plan_from_desc(rq_engine *e, const rq_round_desc *d, rq_plan &p) {
-    if (!e || !d || d->struct_size != sizeof(rq_round_desc)) return RQ_E_ARG;
+// The descriptor as this build knows it: a caller built against 0.2.x headers
+// hands over the struct without the segment table.
+int full_desc(const rq_round_desc *d, rq_round_desc &full) {
+    if (!d || (d->struct_size != sizeof(rq_round_desc) && d->struct_size != RQ_ROUND_DESC_SIZE_V2)) return RQ_E_ARG;
+    std::memset(&full, 0, sizeof full);
+    std::memcpy(&full, d, d->struct_size);
+    full.struct_size = sizeof(rq_round_desc);
+    return RQ_OK;
+}
+
+int segs_from_desc(const rq_round_desc &d, rq_plan &p) {
+    p.segmented = false;
+    std::memset(&p.segs, 0, sizeof p.segs);
+    if (d.n_segments == 0) return RQ_OK;
+    if (d.n_segments > RQ_MAX_SEGMENTS) return RQ_E_ARG;
+    static_assert(RQ_MAX_SEGMENTS == RQ_MAX_SEGS, "segment table sizes");
+    p.segs.count = d.n_segments;
+    if (d.seg_first_group[0] != 0 || d.seg_first_group[d.n_segments] != d.G) return RQ_E_ARG;
+    for (uint32_t i = 0; i < d.n_segments; i++) {
+        if (d.seg_first_group[i + 1] < d.seg_first_group[i]) return RQ_E_ARG;
+        if (i + 1 < d.n_segments && (d.seg_first_group[i + 1] & 63u)) return RQ_E_ARG;
+        if (d.seg_n[i] > 9 || d.seg_n[i] > d.n) return RQ_E_ARG;
+        p.segs.first_group[i] = d.seg_first_group[i];
+        p.segs.n[i] = d.seg_n[i];
+    }
+    p.segs.first_group[d.n_segments] = d.G;
+    if ((d.variant & RQ_VARIANT_PLAIN) && !d.old_mask) return RQ_E_ARG;   // that build decides through the masks
+    p.segmented = true;
+    return RQ_OK;
+}
+
+int plan_from_desc(rq_engine *e, const rq_round_desc *dp, rq_plan &p) {
+    rq_round_desc full;
+    if (!e) return RQ_E_ARG;
+    RQ_TRY(full_desc(dp, full));
+    const rq_round_desc *d = &full;
     p.engine = e; p.n = d->n; p.joint = d->old_mask != nullptr; p.variant = d->variant; p.what = (int)d->what;
+    p.images = 0; p.many = nullptr; p.table = nullptr;
     std::memset(&p.args, 0, sizeof p.args);
     std::memset(&p.args64, 0, sizeof p.args64);
+    RQ_TRY(segs_from_desc(*d, p));
     if (d->layout == RQ_LAYOUT_I32) { p.wide = false; return round_args_from_desc(*d, p.args); }
     if (d->layout == RQ_LAYOUT_I64) { p.wide = true; return round_args_from_desc(*d, p.args64); }
     return RQ_E_ARG;
@@ -356,8 +402,19 @@ int plan_from_desc(rq_engine *e, const rq_round_desc *d, rq_plan &p) {
 int launch_plan(const rq_plan &p, void *stream) {
     rq_engine *e = p.engine;
     RQ_HIP(e, hipSetDevice(e->device));
-    hipError_t err = p.wide ? rq_launch_round(p.args64, p.n, p.joint, p.what, p.variant, (hipStream_t)stream)
-                            : rq_launch_round(p.args, p.n, p.joint, p.what, p.variant, (hipStream_t)stream);
+    if (p.images) {
+        hipError_t err = p.wide
+            ? rq_launch_rounds((const rq_round64_args *)p.many, p.image_n, p.image_joint, p.images,
+                               (const rq_round64_args *)p.table, p.what, p.variant, (hipStream_t)stream)
+            : rq_launch_rounds((const rq_round_args *)p.many, p.image_n, p.image_joint, p.images,
+                               (const rq_round_args *)p.table, p.what, p.variant, (hipStream_t)stream);
+        if (err == hipErrorInvalidValue) return RQ_E_ARG;
+        RQ_HIP(e, err);
+        return RQ_OK;
+    }
+    const rq_round_segs *segs = p.segmented ? &p.segs : nullptr;
+    hipError_t err = p.wide ? rq_launch_round(p.args64, p.n, p.joint, p.what, p.variant, (hipStream_t)stream, segs)
+                            : rq_launch_round(p.args, p.n, p.joint, p.what, p.variant, (hipStream_t)stream, segs);
     if (err == hipErrorInvalidValue) return RQ_E_ARG;
     RQ_HIP(e, err);
     return RQ_OK;
@@ -489,8 +546,9 @@ int append_check_dev(rq_engine *e, void *stream, const rq_append_desc &d) {
     rq_round_args_t<T> r;
     const rq_round_args_t<T> *rp = nullptr;
     if (d.commit_round) {                          // the leader's commit rule in the same launch
-        const rq_round_desc &c = *d.commit_round;
-        if (c.struct_size != sizeof(rq_round_desc) || c.layout != d.layout || c.what != RQ_ROUND_COMMIT) return RQ_E_ARG;
+        rq_round_desc c;
+        RQ_TRY(full_desc(d.commit_round, c));
+        if (c.layout != d.layout || c.what != RQ_ROUND_COMMIT || c.n_segments != 0) return RQ_E_ARG;
         RQ_TRY(round_args_from_desc(c, r));
         rp = &r;
     }
@@ -938,6 +996,48 @@ int rq_plan_round(rq_engine *e, const rq_round_desc *d, rq_plan **out) {
     return RQ_OK;
 }
 
+int rq_plan_rounds(rq_engine *e, const rq_round_desc *descs, uint32_t count, rq_plan **out) {
+    if (!out) return RQ_E_ARG;
+    *out = nullptr;
+    if (!e || !descs || count < 1 || count > RQ_MAX_SEGMENTS) return RQ_E_ARG;
+    rq_plan *p = new (std::nothrow) rq_plan;
+    if (!p) return RQ_E_NOMEM;
+    std::memset(p, 0, sizeof *p);
+    p->engine = e;
+    const bool wide = descs[0].layout == RQ_LAYOUT_I64;
+    const size_t each = wide ? sizeof(rq_round64_args) : sizeof(rq_round_args);
+    p->many = std::malloc(each * count);
+    int rc = p->many ? RQ_OK : RQ_E_NOMEM;
+    for (uint32_t i = 0; i < count && rc == RQ_OK; i++) {
+        // every image: one layout, one decision set, one build; no segment table, no start
+        // signal beyond the first image's (a launch starts once)
+        rq_plan one;
+        rc = plan_from_desc(e, (const rq_round_desc *)((const char *)descs + (size_t)i * descs[0].struct_size), one);
+        if (rc != RQ_OK) break;
+        const rq_round_desc &d = *(const rq_round_desc *)((const char *)descs + (size_t)i * descs[0].struct_size);
+        if (d.struct_size != descs[0].struct_size || d.layout != descs[0].layout || d.what != descs[0].what ||
+            d.variant != descs[0].variant || (d.variant & RQ_VARIANT_PLAIN) || one.segmented ||
+            (i > 0 && d.start_signal)) { rc = RQ_E_ARG; break; }
+        p->image_n[i] = one.n; p->image_joint[i] = one.joint;
+        if (wide) ((rq_round64_args *)p->many)[i] = one.args64; else ((rq_round_args *)p->many)[i] = one.args;
+    }
+    if (rc == RQ_OK) {
+        p->wide = wide; p->images = count; p->what = (int)descs[0].what; p->variant = descs[0].variant;
+        hipError_t err = hipSetDevice(e->device);
+        if (err == hipSuccess) err = hipMalloc(&p->table, each * count);
+        if (err == hipSuccess) err = hipMemcpy(p->table, p->many, each * count, hipMemcpyHostToDevice);
+        if (err != hipSuccess) { e->last_hip.store((int)err); rc = err == hipErrorOutOfMemory ? RQ_E_NOMEM : RQ_E_HIP; }
+    }
+    if (rc != RQ_OK) {
+        if (p->table) (void)hipFree(p->table);
+        std::free(p->many);
+        delete p;
+        return rc;
+    }
+    *out = p;
+    return RQ_OK;
+}
+
 int rq_plan_launch(rq_plan *p, void *stream) {
     if (!p) return RQ_E_ARG;
     return launch_plan(*p, stream);
@@ -994,6 +1094,11 @@ int rq_summary_apply_dev(rq_engine *e, void *stream, const void *gathered, uint6
 
 int rq_plan_destroy(rq_plan *p) {
     if (!p) return RQ_E_ARG;
+    if (p->table) {
+        (void)hipSetDevice(p->engine->device);
+        (void)hipFree(p->table);
+    }
+    std::free(p->many);
     delete p;
     return RQ_OK;
 }

@@ -81,14 +81,39 @@ typedef rq_round_args_t<int64_t> rq_round64_args;
 #define RQ_WHAT_COMMIT 1
 #define RQ_WHAT_VOTE   2
 
+// Segment table of one round (may be absent: count == 0).  The groups
+// [first_group[s], first_group[s + 1]) all have the SAME fixed cluster size n[s]
+// (1..9: their member masks, if the round has any, are old == new == the n[s] lowest
+// slots -- the caller vouches for it) or, with n[s] == 0, are decided through their
+// member masks.  The segments cover [0, G) in order; every boundary but the last
+// is a multiple of 64.  A host that keeps groups of different sizes in one image
+// orders them by size; the fixed-size segments then run the register networks of
+// the fixed-size round inside the same launch and only the rest pays for masks.
+#define RQ_MAX_SEGS 16
+struct rq_round_segs {
+    uint32_t count;
+    uint32_t first_group[RQ_MAX_SEGS + 1];
+    uint8_t n[RQ_MAX_SEGS];
+};
+
 // Enqueue one round on `stream`.  `what` = RQ_WHAT_COMMIT | RQ_WHAT_VOTE.
 // n is the fixed cluster size (1..16) or, with joint = true, ignored in favour
 // of a.m and the masks.  Returns hipErrorInvalidValue for shapes it rejects.
+// segs: null or a table with count >= 1 (then joint must be true: a.m planes).
 hipError_t rq_launch_round(const rq_round_args &a, uint32_t n, bool joint,
-                           int what, int variant, hipStream_t stream);
+                           int what, int variant, hipStream_t stream, const rq_round_segs *segs = nullptr);
 // The same round over 64-bit planes.
 hipError_t rq_launch_round(const rq_round64_args &a, uint32_t n, bool joint,
-                           int what, int variant, hipStream_t stream);
+                           int what, int variant, hipStream_t stream, const rq_round_segs *segs = nullptr);
+
+// Several independent images decided by ONE grid (short rounds share one ramp-up and
+// one drain; images of different cluster sizes each keep their own compact tiles).
+// args / n / joint: image i as rq_launch_round takes it (host memory); table: the same
+// `count` (1..RQ_MAX_SEGS) argument structs in device memory.  variant: block size bits only.
+hipError_t rq_launch_rounds(const rq_round_args *args, const uint32_t *n, const bool *joint, uint32_t count,
+                            const rq_round_args *table, int what, int variant, hipStream_t stream);
+hipError_t rq_launch_rounds(const rq_round64_args *args, const uint32_t *n, const bool *joint, uint32_t count,
+                            const rq_round64_args *table, int what, int variant, hipStream_t stream);
 
 // AppendEntries receiver-side consistency batch (raft.go:142-153) plus the
 // leader's nextIndex/matchIndex bookkeeping for the replies.  Slot id

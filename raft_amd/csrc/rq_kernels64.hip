@@ -5,8 +5,13 @@
 #include "rq_groups_impl.h"
 
 hipError_t rq_launch_round(const rq_round64_args &args, uint32_t n, bool joint, int what,
-                           int variant, hipStream_t stream) {
-    return launch_round_impl<int64_t>(args, n, joint, what, variant, stream);
+                           int variant, hipStream_t stream, const rq_round_segs *segs) {
+    return launch_round_impl<int64_t>(args, n, joint, what, variant, stream, segs);
+}
+
+hipError_t rq_launch_rounds(const rq_round64_args *args, const uint32_t *n, const bool *joint, uint32_t count,
+                            const rq_round64_args *table, int what, int variant, hipStream_t stream) {
+    return launch_rounds_impl<int64_t>(args, n, joint, count, table, what, variant, stream);
 }
 
 hipError_t rq_launch_append_check(const rq_append64_args &a, const rq_round64_args *commit_round, hipStream_t stream) {

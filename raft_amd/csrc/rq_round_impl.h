@@ -17,6 +17,8 @@
 
 #include "rq_kernels.h"
 
+#include <algorithm>
+#include <cstring>
 #include <limits>
 #include <type_traits>
 
@@ -600,7 +602,9 @@ __device__ __forceinline__ T masked_quorum(const T (&mt)[MMAX][V], int k, uint32
 // per-group membership: m slot planes, old/new member masks (joint consensus,
 // mixed cluster sizes).  Null masks mean "all m slots, one configuration".
 // ---------------------------------------------------------------------------
-template <int MMAX, int V, int WHAT, bool NT, bool NTG, bool FULL, typename T>
+// LATE_VOTE: the vote side's first chunk of loads is issued after the commit side's
+// sort instead of before it -- fewer loads in flight, a third fewer registers.
+template <int MMAX, int V, int WHAT, bool NT, bool NTG, bool FULL, typename T, bool LATE_VOTE = false>
 __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T> &a,
                                                      uint32_t g0, int valid,
                                                      bool in_range) {
@@ -710,7 +714,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             ld_i32<V, NTL, FULL>(at(a.cand_term, ga), valid, ct);
             ld_i32<V, NTL, FULL>(at(a.cand_id, ga), valid, ci);
         }
-        issue_chunk(0);
+        if constexpr (!LATE_VOTE) issue_chunk(0);
     }
 
     T nq[V], gt[V], cm[V], lt[V], ts[V];
@@ -783,6 +787,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
     }
 
     if constexpr (DO_VOTE) {
+        if constexpr (LATE_VOTE) issue_chunk(0);
         compute_chunk(0);
         if constexpr (MMAX > kChunk) {
             if ((wm >> kChunk) != 0u) {          // wave-uniform: some lane has a slot >= kChunk
@@ -908,13 +913,126 @@ hipError_t launch_joint_what(const rq_round_args_t<T> &a, int what, int policy, 
     }
 }
 
+// ---------------------------------------------------------------------------
+// Several sub-rounds in one launch.  Sub-round s decides the groups
+// [first_group[s], end_group[s]) of an image with the fixed-size body of kind[s]
+// (1..9: the same code as rq_round_fixed<n>) or, kind 0, with the member-mask
+// body; blocks are dealt to the sub-rounds in order, ceil(len / blockDim) each,
+// and every first_group is a multiple of 64, so a wave never straddles two.
+// Two uses: ONE image whose groups are ordered by cluster size (the segment
+// table of a round; every sub-round reads the launch's own arguments), and
+// SEVERAL images -- each with its own arrays, tiling and size -- decided by one
+// grid (`table` in device memory, sub-round s reads table[image[s]]), so that
+// short rounds share one ramp-up and one drain.  Finding the sub-round and
+// fetching its arguments is scalar work.
+// ---------------------------------------------------------------------------
+struct multi_subs {
+    uint32_t count;
+    uint32_t first_block[RQ_MAX_SEGS + 1];
+    uint32_t first_group[RQ_MAX_SEGS];
+    uint32_t end_group[RQ_MAX_SEGS];
+    uint8_t kind[RQ_MAX_SEGS];
+    uint8_t image[RQ_MAX_SEGS];
+};
+
+template <int WHAT, bool NT, bool NTG, typename T>
+__global__ __launch_bounds__(kBlock) void rq_round_multi(rq_round_args_t<T> a0,
+                                                         const rq_round_args_t<T> *__restrict__ table,
+                                                         multi_subs sb) {
+    signal_started(a0);
+    uint32_t fb = 0, fg = sb.first_group[0], end = sb.end_group[0], kind = sb.kind[0], img = sb.image[0];
+#pragma unroll
+    for (int i = 1; i < RQ_MAX_SEGS; i++) {
+        if (i < (int)sb.count && blockIdx.x >= sb.first_block[i]) {
+            fb = sb.first_block[i]; fg = sb.first_group[i]; end = sb.end_group[i]; kind = sb.kind[i]; img = sb.image[i];
+        }
+    }
+    rq_round_args_t<T> a = a0;
+    if (table) a = table[img];
+    const uint32_t g = fg + (blockIdx.x - fb) * blockDim.x + threadIdx.x;
+    const bool in = g < end;
+    round_fields f{0, 0, 0, 0};
+    switch (kind) {
+#define RQ_SUB_CASE(N) case N: if (in) f = round_fixed_body<N, 1, WHAT, NT, NTG, true>(a, g, 1); break;
+    RQ_SUB_CASE(1) RQ_SUB_CASE(2) RQ_SUB_CASE(3) RQ_SUB_CASE(4) RQ_SUB_CASE(5)
+    RQ_SUB_CASE(6) RQ_SUB_CASE(7) RQ_SUB_CASE(8) RQ_SUB_CASE(9)
+#undef RQ_SUB_CASE
+    default:   // every lane runs the member-mask body: its wave-wide ballots need all of them
+        f = round_joint_body<16, 1, WHAT, NT, NTG, true, T, true>(a, in ? g : 0u, in ? 1 : 0, in);
+    }
+    if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
+        if (a.elected_bits) pack_elected<1>(f.elected, g, end, a.elected_bits);
+    }
+    if (a.changed_bits) pack_elected<1>(f.changed, g, end, a.changed_bits);
+    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
+        if (a.commit_lo16 && a.summary_bits == 4)
+            pack_nibbles<1>(f.nibbles, g, end, reinterpret_cast<uint64_t *>(a.commit_lo16));
+        if (a.commit_lo16 && a.summary_escapes) count_escapes(f.escapes, a.summary_escapes);
+    }
+}
+
+// Deals blocks to the sub-rounds and enqueues the grid.  The sub-rounds whose waves live
+// longest get the first blocks -- member masks (one more dependent load), then the fixed
+// sizes from 9 down -- so that the grid drains through its shortest waves.
+template <int WHAT, typename T>
+hipError_t launch_multi(const rq_round_args_t<T> &a0, const rq_round_args_t<T> *table, const multi_subs &in, int policy,
+                        uint32_t block, hipStream_t s) {
+    uint32_t order[RQ_MAX_SEGS];
+    for (uint32_t i = 0; i < in.count; i++) order[i] = i;
+    auto weight = [&](uint32_t i) { return in.kind[i] ? (uint32_t)in.kind[i] : 100u; };
+    std::stable_sort(order, order + in.count, [&](uint32_t x, uint32_t y) { return weight(x) > weight(y); });
+    multi_subs sb;
+    std::memset(&sb, 0, sizeof sb);
+    sb.count = in.count;
+    uint64_t nb = 0;
+    for (uint32_t i = 0; i < in.count; i++) {
+        const uint32_t j = order[i];
+        sb.first_group[i] = in.first_group[j]; sb.end_group[i] = in.end_group[j];
+        sb.kind[i] = in.kind[j]; sb.image[i] = in.image[j];
+        sb.first_block[i] = (uint32_t)nb;
+        nb += ((uint64_t)(sb.end_group[i] - sb.first_group[i]) + block - 1) / block;
+    }
+    for (uint32_t i = sb.count; i <= RQ_MAX_SEGS; i++) sb.first_block[i] = (uint32_t)nb;
+    if (nb == 0) return hipSuccess;
+    if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
+        if (policy == 1) {
+            hipLaunchKernelGGL((rq_round_multi<WHAT, true, false, T>), dim3((uint32_t)nb), dim3(block), 0, s, a0, table, sb);
+            return hipGetLastError();
+        }
+    }
+    hipLaunchKernelGGL((rq_round_multi<WHAT, true, true, T>), dim3((uint32_t)nb), dim3(block), 0, s, a0, table, sb);
+    return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_multi_what(const rq_round_args_t<T> &a0, const rq_round_args_t<T> *table, const multi_subs &sb,
+                             int what, int policy, uint32_t block, hipStream_t s) {
+    switch (what) {
+    case RQ_WHAT_COMMIT: return launch_multi<RQ_WHAT_COMMIT>(a0, table, sb, policy, block, s);
+    case RQ_WHAT_VOTE: return launch_multi<RQ_WHAT_VOTE>(a0, table, sb, policy, block, s);
+    default: return launch_multi<RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a0, table, sb, policy, block, s);
+    }
+}
+
+// The table is usable when it covers [0, G) in order with 64-aligned inner
+// boundaries and every fixed size fits the image's planes.
+inline bool segs_ok(const rq_round_segs &t, uint32_t G, uint32_t m) {
+    if (t.count < 1 || t.count > RQ_MAX_SEGS || t.first_group[0] != 0 || t.first_group[t.count] != G) return false;
+    for (uint32_t i = 0; i < t.count; i++) {
+        if (t.first_group[i + 1] < t.first_group[i]) return false;
+        if (i + 1 < t.count && (t.first_group[i + 1] & 63u)) return false;
+        if (t.n[i] > 9 || t.n[i] > m) return false;
+    }
+    return true;
+}
+
 inline bool aligned_to(const void *p, size_t a) {
     return p == nullptr || (reinterpret_cast<uintptr_t>(p) & (a - 1)) == 0;
 }
 
 template <typename T>
 hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool joint, int what,
-                             int variant, hipStream_t stream) {
+                             int variant, hipStream_t stream, const rq_round_segs *segs = nullptr) {
     if (args.G == 0) return hipSuccess;
     if (args.G > 0x7FFFFFFFu || (args.ld < args.G && !args.tile_bytes)) return hipErrorInvalidValue;
     if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE))) return hipErrorInvalidValue;
@@ -934,9 +1052,32 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if (variant & RQ_VAR_PLAIN) policy = 0;
     else if ((what & RQ_WHAT_COMMIT) &&
              args.log_terms * (tb / 8) > kNtGatherMaxArenaBytesPerGroup * (uint64_t)args.G) policy = 1;
+    if (segs) {
+        // Groups ordered by size in an image of n planes; member masks are needed only by
+        // segments of kind 0 (without masks those take all n slots as their one configuration).
+        rq_round_args_t<T> b = args;
+        b.m = n;
+        if (!joint) { b.old_mask = nullptr; b.new_mask = nullptr; }
+        if (n < 1 || n > 16 || !segs_ok(*segs, b.G, n)) return hipErrorInvalidValue;
+        if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
+        // The table never changes a result, only which code decides a group: the plain
+        // cache policy has no segmented build and decides every group through its masks.
+        if (policy != 0) {
+            multi_subs sb;
+            std::memset(&sb, 0, sizeof sb);
+            sb.count = segs->count;
+            for (uint32_t i = 0; i < segs->count; i++) {
+                sb.first_group[i] = segs->first_group[i];
+                sb.end_group[i] = segs->first_group[i + 1];
+                sb.kind[i] = segs->n[i];
+            }
+            return launch_multi_what<T>(b, nullptr, sb, what, policy, bsel ? block : (uint32_t)kDefaultBlockFixed, stream);
+        }
+        if (!joint) return hipErrorInvalidValue;
+    }
     const rq_round_args_t<T> &a = args;
 
-    if (fixed) {
+    if (fixed && !segs) {
         switch (n) {
         case 1: return launch_fixed_what<1>(a, what, policy, block, stream);
         case 2: return launch_fixed_what<2>(a, what, policy, block, stream);
@@ -956,6 +1097,34 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
     if (b.m <= 8) return launch_joint_what<8>(b, what, policy, block, stream);
     return launch_joint_what<16>(b, what, policy, block, stream);
+}
+
+// Several images in one grid.  args[i] / n[i] / joint[i]: image i as rq_launch_round takes it;
+// table: the same `count` argument structs in device memory (the caller keeps them there).
+template <typename T>
+hipError_t launch_rounds_impl(const rq_round_args_t<T> *args, const uint32_t *n, const bool *joint, uint32_t count,
+                              const rq_round_args_t<T> *table, int what, int variant, hipStream_t stream) {
+    if (count < 1 || count > RQ_MAX_SEGS || !table) return hipErrorInvalidValue;
+    if (!(what & (RQ_WHAT_COMMIT | RQ_WHAT_VOTE)) || (variant & ~0xF00)) return hipErrorInvalidValue;
+    const int bsel = (variant >> 8) & 0xF;
+    if (bsel > 4) return hipErrorInvalidValue;
+    multi_subs sb;
+    std::memset(&sb, 0, sizeof sb);
+    sb.count = count;
+    uint64_t arena_bytes = 0, groups = 0;
+    for (uint32_t i = 0; i < count; i++) {
+        const rq_round_args_t<T> &a = args[i];
+        if (a.G > 0x7FFFFFFFu || (a.ld < a.G && !a.tile_bytes)) return hipErrorInvalidValue;
+        const bool fixed = !joint[i] && n[i] >= 1 && n[i] <= 9;
+        if (!fixed && (a.m < 1 || a.m > 16 || (a.old_mask == nullptr) != (a.new_mask == nullptr))) return hipErrorInvalidValue;
+        sb.first_group[i] = 0; sb.end_group[i] = a.G;
+        sb.kind[i] = fixed ? (uint8_t)n[i] : 0;
+        sb.image[i] = (uint8_t)i;
+        arena_bytes += a.log_terms * (a.log_term_bits / 8);
+        groups += a.G;
+    }
+    const int policy = ((what & RQ_WHAT_COMMIT) && arena_bytes > kNtGatherMaxArenaBytesPerGroup * groups) ? 1 : 2;
+    return launch_multi_what<T>(args[0], table, sb, what, policy, bsel ? 64u * (uint32_t)bsel : (uint32_t)kDefaultBlockFixed, stream);
 }
 
 }  // namespace

@@ -189,7 +189,7 @@ class DeviceBatch:
     def __init__(self, batch, device="cuda:0", in_place=False, commit_out=None, elected_bits=None,
                  share_log_with=None, commit_lo16=None, summary_escapes=None, summary_base=None,
                  summary_bits=16, log_term_bits=None, log_term_base=False, tiled=False, start_signal=None,
-                 term_start=False):
+                 term_start=False, segments=None, own_log_off=False):
         """commit_out / elected_bits: optional preallocated device views (e.g. a
         sharded.SummaryExchange slot) for the kernel to write its summary into.
         share_log_with: another DeviceBatch whose log_off/log_term device arrays
@@ -211,8 +211,13 @@ class DeviceBatch:
         term_start=True: no log arena on the device at all -- per group the index of the
         first entry of the leader's term and the log length (synth.term_start_form, or
         the two arrays themselves; the batch's logs must be non-decreasing and not
-        above the leader's term)."""
+        above the leader's term).
+        own_log_off: with share_log_with, share only the arena; this batch's offsets into it
+        are its own (synth.split_by_size images).
+        segments: (first_group, n) as synth.segment_table returns it -- the groups are
+        ordered by cluster size and every launch says so (rq_round_desc.n_segments)."""
         self.start_signal = start_signal
+        self.segments = segments
         self.G, self.n, self.ld = int(batch["G"]), int(batch["n"]), int(batch["ld"])
         self.device = torch.device(device)
         G, n, ld = self.G, self.n, self.ld
@@ -241,7 +246,7 @@ class DeviceBatch:
         for k in self.IN_KEYS:
             if term_start and k in ("log_off", "log_term", "leader_term"):
                 continue                        # not read by a round that knows where the term starts
-            if share_log_with is not None and (k == "log_term" or (k == "log_off" and not tiled)):
+            if share_log_with is not None and (k == "log_term" or (k == "log_off" and not tiled and not own_log_off)):
                 continue                        # (a tiled batch keeps its offsets inside its own tiles)
             a = batch[k]
             if k == "log_term" and enc_term is not None:
@@ -278,7 +283,7 @@ class DeviceBatch:
             for k, shape, dt in outs:
                 o[k] = torch.zeros(shape, dtype=dt, device=self.device)
         if share_log_with is not None:
-            if not tiled:
+            if not tiled and not own_log_off:
                 self.t["log_off"] = share_log_with.t["log_off"]
             self.t["log_term"] = share_log_with.t["log_term"]
             if "log_term_base" in share_log_with.t:
@@ -492,6 +497,14 @@ class DeviceEngine:
         d.status_out = p(o["status"]) if status else None
         d.changed_bits = p(o.get("changed_bits"))
         d.start_signal = b.start_signal
+        segs = getattr(b, "segments", None)
+        if segs is not None:
+            first, kinds = segs
+            d.n_segments = len(kinds)
+            for i, v in enumerate(first):
+                d.seg_first_group[i] = v
+            for i, v in enumerate(kinds):
+                d.seg_n[i] = v
         return d
 
     def round(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
@@ -508,6 +521,25 @@ class DeviceEngine:
                 self._check(rc, "rq_plan_round")
             b._args[key] = plan
             b._plans.append((self._l, plan))
+        rc = self._l.rq_plan_launch(plan, torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            self._check(rc, "rq_plan_launch")
+
+    def plan_rounds(self, batches, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """ONE prepared launch over several DeviceBatch images (rq_plan_rounds): each keeps its
+        own arrays, cluster size or member masks and tiling.  Returns a handle for launch_plan();
+        the plan is destroyed with the first batch."""
+        descs = (RoundDesc * len(batches))()
+        for i, b in enumerate(batches):
+            descs[i] = self.describe(b, what, variant, want_bits, status)
+        plan = C.c_void_p()
+        rc = self._l.rq_plan_rounds(self._h, descs, len(batches), C.byref(plan))
+        if rc != 0:
+            self._check(rc, "rq_plan_rounds")
+        batches[0]._plans.append((self._l, plan))
+        return plan
+
+    def launch_plan(self, plan):
         rc = self._l.rq_plan_launch(plan, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             self._check(rc, "rq_plan_launch")

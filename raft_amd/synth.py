@@ -179,7 +179,9 @@ def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi
     configurations overlapping in at least one slot, all within 16 slots),
     Zipf(1.2) log lengths clipped to [1, 4096].  bucketed=True orders groups by
     highest member slot so that waves are homogeneous (a host-side layout
-    choice; results do not depend on it).  logs_from: a previous gen_mixed batch
+    choice; results do not depend on it); bucketed="size" orders them by cluster
+    size with the groups in joint consensus last, the order segment_table()
+    describes to a segmented launch.  logs_from: a previous gen_mixed batch
     whose log arena (hundreds of MB at 1M groups) is reused unchanged."""
     m = 16
     g = np.arange(G, dtype=np.int64)
@@ -192,6 +194,8 @@ def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi
     new_mask = np.where(is_joint, ((1 << n_new) - 1) << shift, old_mask)
     if bucketed:
         top = np.floor(np.log2((old_mask | new_mask).astype(np.float64))).astype(np.int64)
+        if bucketed == "size":
+            top = np.where(old_mask == new_mask, n_old, 32 + top)
         order = np.argsort(top, kind="stable")
         old_mask, new_mask = old_mask[order], new_mask[order]
     old_mask = old_mask.astype(np.uint16); new_mask = new_mask.astype(np.uint16)
@@ -212,6 +216,71 @@ def gen_mixed(G, seed=DEFAULT_SEED, joint_frac=0.10, bucketed=True, n_lo=3, n_hi
                  log_off=off, log_term=log_term, voter_term=vt, voted_for=vf,
                  last_log_term=ll, cand_term=ct, cand_id=ci, old_mask=old_mask, new_mask=new_mask,
                  log_T=T)
+
+
+def segment_table(old_mask, new_mask, max_segments=16):
+    """(first_group, n): the segment table of rq_round_desc for an image whose groups are
+    ordered by cluster size.  A 64-group tile whose groups all have old == new == the n
+    lowest slots for one n in 1..9 belongs to a fixed-size segment of that n; every other
+    tile (joint consensus, two sizes meeting, other member sets) to a segment of kind 0,
+    decided through the masks.  Neighbouring tiles of one kind are merged.  Returns None
+    when the order of the groups needs more than max_segments segments."""
+    om = np.asarray(old_mask).astype(np.int64)
+    nm = np.asarray(new_mask).astype(np.int64)
+    G = om.size
+    if G == 0:
+        return None
+    n = np.zeros(G, np.int64)
+    for k in range(1, 10):
+        n[(om == nm) & (om == (1 << k) - 1)] = k
+    ntiles = (G + 63) // 64
+    pad = np.full(ntiles * 64, -1, np.int64)
+    pad[:G] = n
+    tiles = pad.reshape(ntiles, 64)
+    first = tiles[:, 0]
+    same = ((tiles == first[:, None]) | (tiles == -1)).all(axis=1)
+    kind = np.where(same, first, 0)
+    starts = np.concatenate([[0], 1 + np.flatnonzero(kind[1:] != kind[:-1])])
+    if starts.size > max_segments:
+        return None
+    first_group = [int(t) * 64 for t in starts] + [G]
+    return first_group, [int(kind[t]) for t in starts]
+
+
+def split_by_size(b, max_images=16):
+    """A mixed batch ordered by cluster size (gen_mixed(bucketed="size")) as separate
+    images, one per run of equal kind: [(kind, lo, hi, sub-batch)].  kind n = 1..9: the
+    groups lo..hi-1 are all plain clusters of n peers; the sub-batch has n slot planes
+    and no member masks (a fixed-size round).  kind 0: everything else, with its masks
+    and all the slot planes.  The sub-batches index the ORIGINAL log arena (log_off
+    keeps its absolute offsets), so one resident arena serves every image.  Returns
+    None when the order of the groups needs more than max_images runs."""
+    G = int(b["G"])
+    om = np.asarray(b["old_mask"]).astype(np.int64)
+    nm = np.asarray(b["new_mask"]).astype(np.int64)
+    kind = np.zeros(G, np.int64)
+    for k in range(1, 10):
+        kind[(om == nm) & (om == (1 << k) - 1)] = k
+    starts = np.concatenate([[0], 1 + np.flatnonzero(kind[1:] != kind[:-1]), [G]])
+    if starts.size - 1 > max_images:
+        return None
+    per_slot = ("match", "voter_term", "voted_for", "last_log_term")
+    per_group = ("commit", "leader_term", "cand_term", "cand_id", "log_base", "log_T")
+    out = []
+    for lo, hi in zip(starts[:-1], starts[1:]):
+        lo, hi = int(lo), int(hi)
+        k = int(kind[lo])
+        slots = k if k else int(b["n"])
+        sub = Batch(G=hi - lo, n=slots, ld=hi - lo, log_off=b["log_off"][lo:hi + 1], log_term=b["log_term"])
+        for f in per_slot:
+            sub[f] = np.ascontiguousarray(np.asarray(b[f])[:slots, lo:hi])
+        for f in per_group:
+            if f in b:
+                sub[f] = np.asarray(b[f])[lo:hi]
+        if not k:
+            sub["old_mask"], sub["new_mask"] = b["old_mask"][lo:hi], b["new_mask"][lo:hi]
+        out.append((k, lo, hi, sub))
+    return out
 
 
 def raft_valid(b):

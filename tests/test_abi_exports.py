@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
 def test_version_and_strerror():
     from raft_amd import _lib
     l = _lib.lib()
-    assert l.rq_version() == 0x000204
+    assert l.rq_version() == 0x000300
     assert l.rq_strerror(0) == b"ok"
     for code in range(-8, 0):
         assert l.rq_strerror(code) not in (b"", b"unknown rq error")

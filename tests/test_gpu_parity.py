@@ -439,9 +439,195 @@ def test_full_size_1m_mixed_sizes_and_joint_consensus(dev):
         _check_dev(res, exp, G, mem)
         del db
     assert res["commit"].shape == (G,) and (res["commit"] >= b.commit).all()
+    # the same population ordered by cluster size: one image launched with the segment table,
+    # then one image per size in ONE launch (the two layouts bench.py times)
+    bs = synth.gen_mixed(G, seed=2025, bucketed="size", logs_from=b)
+    exps = o.fused_round(*bs.fused_args(), G=G, old_mask=bs.old_mask, new_mask=bs.new_mask)
+    segs = synth.segment_table(bs.old_mask, bs.new_mask)
+    assert len(segs[1]) == 14
+    db = DeviceBatch(bs, tiled=True, segments=segs)
+    dev.fused_round(db)
+    _check_dev(db.results(), exps, G, member_matrix(bs))
+    arena = db
+    imgs = [DeviceBatch(sub, tiled=True, share_log_with=arena, own_log_off=True) for _, _, _, sub in synth.split_by_size(bs)]
+    dev.launch_plan(dev.plan_rounds(imgs))
+    for im, (k, lo, hi, sub) in zip(imgs, synth.split_by_size(bs)):
+        r = im.results()
+        part = {f: (exps[f][:sub.n, lo:hi] if f == "voter_term" else exps[f][lo:hi]) for f in ("commit", "voter_term") + VOTE_FIELDS}
+        _check_dev(r, part, hi - lo, member_matrix(sub) if k == 0 else None)
+    del imgs, arena, db
     joint = b.old_mask != b.new_mask
     assert 0.05 < joint.mean() < 0.15 and 0.05 < (res["commit"] != b.commit).mean() < 0.7
     assert 0.1 < res["elected"].mean() < 0.9 and np.diff(b.log_off.astype(np.int64)).max() == 4096
+
+
+# ---------------------------------------------------------------------------
+# segmented launch: groups ordered by cluster size, the fixed-size segments decided
+# by the fixed-size code inside the same launch (rq_round_desc.n_segments)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("tiled", [False, True])
+def test_segmented_round_equals_the_oracle(dev, tiled):
+    """Mixed 3-9 clusters + joint consensus ordered by size, launched with the segment
+    table: every output of every group equals the oracle's (which knows nothing of
+    segments), for the fused round and for each decision alone, int32 and int64."""
+    from raft_amd.device import DeviceBatch
+    for G, joint_frac in ((1, 0.1), (64, 0.1), (65, 0.0), (5000, 0.1), (70001, 0.1), (150001, 0.3)):
+        b = synth.gen_mixed(G, seed=77 + G, bucketed="size", joint_frac=joint_frac)
+        segs = synth.segment_table(b.old_mask, b.new_mask)
+        assert segs is not None and segs[0][-1] == G
+        if G >= 5000:
+            assert sum(1 for k in segs[1] if k) >= 7, segs        # sizes 3..9 each got a fixed segment
+        exp = o.fused_round(*b.fused_args(), G=G, old_mask=b.old_mask, new_mask=b.new_mask)
+        mem = member_matrix(b)
+        db = DeviceBatch(b, tiled=tiled, segments=segs)
+        dev.fused_round(db)
+        _check_dev(db.results(), exp, G, mem)
+        for what in (1, 2):                                         # one decision per launch
+            db = DeviceBatch(b, tiled=tiled, segments=segs)
+            dev.round(db, what)
+            res = db.results()
+            if what == 1:
+                assert np.array_equal(res["commit"], exp["commit"])
+                assert np.array_equal(res["status"], exp["status"] & 0x05)
+            else:
+                for f in ("grant_mask", "stepdown_mask", "elected", "max_term"):
+                    assert np.array_equal(res[f], exp[f]), f
+                assert np.array_equal(res["voter_term"][:, :G][mem], exp["voter_term"][:, :G][mem])
+        if G in (5000, 70001):
+            w, _ = synth.widen(b, index_shift=1 << 33, term_shift=1 << 41, id_shift=1 << 42, seed=G)
+            wexp = o.round64(3, G=G, **{k: w[k] for k in (
+                "match", "commit", "leader_term", "log_off", "log_term", "voter_term", "voted_for", "last_log_term",
+                "cand_term", "cand_id", "old_mask", "new_mask", "log_base")})
+            db = DeviceBatch(w, tiled=tiled, segments=segs)
+            dev.fused_round(db)
+            _check_dev(db.results(), wexp, G, mem)
+
+
+def test_segmented_round_options(dev):
+    """The segment table with the other options of a launch: no arena (log_term_start), narrow
+    arena entries with per-group bases, changed bits, the 4-bit commit summary, the plain cache
+    policy (which decides every group through its masks) -- the same results as without the table."""
+    import torch
+    from raft_amd.device import DeviceBatch
+    G = 40000
+    b = synth.raft_valid(synth.gen_mixed(G, seed=5150, bucketed="size"))
+    segs = synth.segment_table(b.old_mask, b.new_mask)
+    exp = o.fused_round(*b.fused_args(), G=G, old_mask=b.old_mask, new_mask=b.new_mask)
+    mem = member_matrix(b)
+    for kw in (dict(term_start=True), dict(log_term_bits=0, log_term_base=True), dict(in_place=True)):
+        for tiled in (False, True):
+            db = DeviceBatch(b, tiled=tiled, segments=segs, **kw)
+            dev.fused_round(db)
+            _check_dev(db.results(), exp, G, mem)
+    db = DeviceBatch(b, tiled=True, segments=segs)
+    dev.fused_round(db, variant=1)
+    _check_dev(db.results(), exp, G, mem)
+    # changed bits + advance-coded 4-bit summary, against the same launch without a table
+    outs = []
+    for sg in (segs, None):
+        lo = torch.zeros((G + 15) // 16, dtype=torch.int64, device="cuda:0")
+        esc = torch.zeros(1, dtype=torch.int32, device="cuda:0")
+        db = DeviceBatch(b, tiled=True, segments=sg, commit_lo16=lo, summary_escapes=esc, summary_bits=4, summary_base="commit")
+        db.o["changed_bits"] = torch.zeros((G + 63) // 64, dtype=torch.int64, device="cuda:0")
+        dev.fused_round(db)
+        r = db.results()
+        outs.append((r["commit_lo16"], r["summary_escapes"], db.o["changed_bits"].cpu().numpy()))
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)
+    adv = exp["commit"].astype(np.int64) - b.commit
+    assert np.array_equal(outs[0][0], np.where(adv < 15, adv, 15).astype(np.uint16))
+    ch = np.unpackbits(outs[0][2].view(np.uint8), bitorder="little")[:G].astype(bool)
+    assert np.array_equal(ch, (adv != 0) | (exp["elected"] != 0) | (exp["stepdown_mask"] != 0) | (exp["status"] != 0))
+
+
+def test_segment_table_is_checked_and_a_wrong_one_is_not_a_fault(dev):
+    """Tables that do not cover [0, G) in 64-aligned steps, or name a size beyond the planes,
+    are refused with RQ_E_ARG.  A table that lists groups under the wrong size decides them as
+    clusters of that size (the oracle on the batch with exactly those masks) and reads nothing
+    out of bounds."""
+    import ctypes as C
+    from raft_amd.device import DeviceBatch
+    G = 20000
+    b = synth.gen_mixed(G, seed=31337, bucketed="size")
+    db = DeviceBatch(b, tiled=True)
+    for first, kinds in (([64, G], [3]), ([0, G - 1], [3]), ([0, 100, G], [3, 0]), ([0, 128, 64, G], [3, 4, 5]),
+                         ([0, G], [10]), ([0, 64, G], [3, 17]), ([0] + [64] * 16 + [G], [0] * 17)):
+        d = dev.describe(db)
+        d.n_segments = len(kinds)
+        for i, v in enumerate(first[:17]):
+            d.seg_first_group[i] = v
+        for i, v in enumerate(kinds[:16]):
+            d.seg_n[i] = v
+        assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == -1, (first, kinds)
+    lie = ([0, 6400, G], [4, 0])                 # the first 6400 groups are not all clusters of 4
+    db = DeviceBatch(b, tiled=True, segments=lie)
+    dev.fused_round(db)
+    res = db.results()
+    as_told = synth.Batch(b)
+    om, nm = b.old_mask.copy(), b.new_mask.copy()
+    om[:6400] = nm[:6400] = 0xF
+    exp = o.fused_round(*b.fused_args(), G=G, old_mask=om, new_mask=nm)
+    as_told["old_mask"], as_told["new_mask"] = om, nm
+    _check_dev(res, exp, G, member_matrix(as_told))
+
+
+def test_rounds_in_one_launch(dev):
+    """rq_plan_rounds: one image per cluster size (compact tiles or planes, no masks) plus one
+    with member masks, decided by ONE grid -- every image equals the oracle on its own groups,
+    and the whole equals the oracle on the unsplit batch.  Then four independent fixed-size
+    batches of different shapes in one launch, and the refusals."""
+    import ctypes as C
+    from raft_amd._lib import RoundDesc
+    from raft_amd.device import DeviceBatch
+    for G, tiled in ((65, True), (30011, False), (90001, True)):
+        b = synth.gen_mixed(G, seed=900 + G, bucketed="size")
+        parts = synth.split_by_size(b)
+        assert parts is not None and (G < 1000 or [k for k, _, _, _ in parts] == [3, 4, 5, 6, 7, 8, 9, 0])
+        whole = o.fused_round(*b.fused_args(), G=G, old_mask=b.old_mask, new_mask=b.new_mask)
+        for what in (3, 1, 2):
+            imgs = []
+            for k, lo, hi, sub in parts:
+                imgs.append(DeviceBatch(sub, tiled=tiled, share_log_with=imgs[0] if imgs else None, own_log_off=True))
+            plan = dev.plan_rounds(imgs, what)
+            dev.launch_plan(plan)
+            for db, (k, lo, hi, sub) in zip(imgs, parts):
+                res = db.results()
+                if what & 1:
+                    assert np.array_equal(res["commit"], whole["commit"][lo:hi]), (G, k)
+                if what & 2:
+                    for f in ("grant_mask", "stepdown_mask", "elected", "max_term"):
+                        assert np.array_equal(res[f], whole[f][lo:hi]), (G, k, f)
+                    mem = member_matrix(sub) if k == 0 else np.ones((sub.n, sub.G), bool)
+                    assert np.array_equal(res["voter_term"][:, :sub.G][mem], whole["voter_term"][:sub.n, lo:hi][mem])
+                    bits = np.unpackbits(res["elected_bits"].view(np.uint8), bitorder="little")
+                    assert np.array_equal(bits[:sub.G], whole["elected"][lo:hi]) and not bits[sub.G:].any()
+                if what == 3:
+                    assert np.array_equal(res["status"], whole["status"][lo:hi])
+    # independent batches of different shapes, widths of arena entries and layouts of state
+    bs = [synth.gen_fused(40001, 5, seed=1), synth.gen_adversarial(777, 3, seed=2), synth.gen_fused(64, 9, seed=3),
+          synth.gen_adversarial(5000, 12, seed=4)]
+    imgs = [DeviceBatch(bs[0], tiled=True, log_term_bits=0), DeviceBatch(bs[1]), DeviceBatch(bs[2], tiled=True, in_place=True),
+            DeviceBatch(bs[3], tiled=True)]
+    plan = dev.plan_rounds(imgs)
+    dev.launch_plan(plan)
+    for db, hb in zip(imgs, bs):
+        _check_dev(db.results(), o.fused_round(*hb.fused_args(), G=hb.G), hb.G)
+    # refusals: no images, too many, mixed layouts / decision sets, a segment table inside
+    descs = (RoundDesc * 17)()
+    for i in range(17):
+        descs[i] = dev.describe(imgs[0])
+    out = C.c_void_p()
+    assert dev._l.rq_plan_rounds(dev._h, descs, 0, C.byref(out)) == -1
+    assert dev._l.rq_plan_rounds(dev._h, descs, 17, C.byref(out)) == -1
+    descs[1].what = 1
+    assert dev._l.rq_plan_rounds(dev._h, descs, 2, C.byref(out)) == -1
+    descs[1] = dev.describe(imgs[0]); descs[1].layout = 8
+    assert dev._l.rq_plan_rounds(dev._h, descs, 2, C.byref(out)) == -1
+    descs[1] = dev.describe(imgs[0]); descs[1].n_segments = 1; descs[1].seg_first_group[1] = imgs[0].G; descs[1].seg_n[0] = 5
+    assert dev._l.rq_plan_rounds(dev._h, descs, 2, C.byref(out)) == -1
+    descs[1] = dev.describe(imgs[0]); descs[1].variant = 1; descs[0].variant = 1
+    assert dev._l.rq_plan_rounds(dev._h, descs, 2, C.byref(out)) == -1
+    assert not out.value
 
 
 # ---------------------------------------------------------------------------
