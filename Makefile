@@ -3,7 +3,9 @@
 HIPCC   ?= hipcc
 CC      ?= gcc
 ARCH    ?= gfx950
-HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function
+# PLAIN=1 also builds the round kernels with the default cache policy (RQ_VARIANT_PLAIN;
+# a library without them runs the streaming builds for that variant, results are the same)
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function $(if $(PLAIN),-DRQ_BUILD_PLAIN)
 CSRC     = raft_amd/csrc
 
 all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli examples/rq_bench

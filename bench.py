@@ -117,6 +117,9 @@ def parse():
     ap.add_argument("--log-term-bits", type=int, choices=[0, 8, 16, 32], default=0,
                     help="width of the log-term arena entries; 0 = the narrowest the batch's terms fit "
                          "(what a host keeping the arena resident would choose), 32 = the plain int32 arena")
+    ap.add_argument("--no-segments", action="store_true",
+                    help="mixed workload: groups ordered by highest slot and every group decided through its member "
+                         "masks, instead of ordered by cluster size and launched with the segment table")
     ap.add_argument("--planes", action="store_true",
                     help="keep every array as a slot-major plane field[p * ld + g] instead of the default 64-group "
                          "tiles (rq_round_desc.tile_bytes: one input and one output stream per wave)")
@@ -304,6 +307,17 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches, out):
     out["three_streams"] = dict(ms_per_round=ms, frac_effective=frac(alg_bytes_per_group(n), ms), input_sets=S,
                                 note="the headline rounds dealt to three streams (independent batches): host-clock "
                                      "time per round over 240 launches; launches overlap, so this is not a launch duration")
+    # Several batches decided by ONE grid (rq_plan_rounds): k of the headline's sets per launch share
+    # one ramp-up and one drain.  HIP-event time per launch / k.
+    for k in (4,):
+        plans = [eng.plan_rounds([sets[(j * k + i) % S] for i in range(k)]) for j in range(S // k)]
+        P = len(plans)
+        msk = timed_launches(torch, device, lambda i: eng.launch_plan(plans[i % P]), max(steps // k, 10), max(warmup // k, 2), P)
+        out["rounds_in_one_launch"] = dict(
+            batches_per_launch=k, launch_ms=msk, ms_per_round=msk / k, frac=frac(alg_bytes_per_group(n), msk / k), input_sets=S,
+            note="%d independent 1M x %d batches (the headline's sets) decided by one grid, rq_plan_rounds: HIP-event "
+                 "time of the launch / %d" % (k, n, k), verified=verify_against_oracle(sets[k - 1], host_batches[k - 1]))
+        del plans
     del sets
     torch.cuda.empty_cache()
     # no arena on the device: the host keeps, per group, the index of the first entry of the
@@ -433,35 +447,63 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches, out):
     del wide, whost
     torch.cuda.empty_cache()
 
-    # mixed 3-9 peers + 10 % joint consensus, Zipf log lengths; one log arena shared by the sets
-    first = synth.gen_mixed(G, seed=500)
-    msets = [DeviceBatch(first, device, tiled=tiled)]
-    mstart = [synth.term_start_monotone(first)]
-    mhost = [first]
-    for s in range(1, 8):
-        mb = synth.gen_mixed(G, seed=500 + s, logs_from=first)
-        msets.append(DeviceBatch(mb, device, share_log_with=msets[0], tiled=tiled))
-        mstart.append(synth.term_start_monotone(mb))
-        mb = synth.Batch(mb)
-        mb["log_term"] = first["log_term"][:1]          # the arena is not needed again: let it go
-        mhost.append(mb)
+    # mixed 3-9 peers + 10 % joint consensus, Zipf log lengths; one log arena shared by the sets.  The
+    # host orders the groups by cluster size (groups in joint consensus last) and says so in the
+    # launch descriptor (segment table): the fixed-size segments are decided by the fixed-size code
+    # inside the same launch, only the rest through member masks.
+    first = synth.gen_mixed(G, seed=500, bucketed="size")
+    mhost = [first] + [synth.gen_mixed(G, seed=500 + s, bucketed="size", logs_from=first) for s in range(1, 8)]
+    S = len(mhost)
     mem = (first.old_mask | first.new_mask).astype(np.int64)
     members = float(sum((mem >> p) & 1 for p in range(16)).mean())
     bpg = 20 * members + 41
-    S = len(msets)
+    mnote = "mixed 3-9 peers + 10% joint consensus, Zipf(1.2) logs up to 4096 entries"
+
+    def mixed_sets(**kw):
+        sets = []
+        for i, mb in enumerate(mhost):
+            if "term_start" not in kw and i:
+                sets.append(DeviceBatch(mb, device, tiled=tiled, share_log_with=sets[0], **kw))
+            else:
+                sets.append(DeviceBatch(mb, device, tiled=tiled, **kw))
+        return sets
+
+    msets = mixed_sets()
+    for db, mb in zip(msets, mhost):
+        db.segments = synth.segment_table(mb.old_mask, mb.new_mask)
     ms = timed_launches(torch, device, lambda i: eng.fused_round(msets[i % S]), steps, warmup, S)
     out["mixed"] = dict(kernel_ms=ms, frac=frac(bpg, ms), input_sets=S, alg_bytes_per_group=bpg,
-                        mean_member_slots=members,
-                        note="mixed 3-9 peers + 10% joint consensus, Zipf(1.2) logs up to 4096 entries",
+                        mean_member_slots=members, segments=len(msets[0].segments[1]),
+                        note=mnote + "; ONE image ordered by cluster size, launched with the segment table",
                         verified=verify_against_oracle(msets[0], first))
-    del msets
+    # the same images decided through the member masks alone (no table): what every group cost before
+    for db in msets:
+        db.segments, db._args = None, {}
+    ms = timed_launches(torch, device, lambda i: eng.fused_round(msets[i % S]), steps, warmup, S)
+    out["mixed_masks_only"] = dict(kernel_ms=ms, frac=frac(bpg, ms), input_sets=S, alg_bytes_per_group=bpg,
+                                   note=mnote + "; every group decided through its member masks",
+                                   verified=verify_against_oracle(msets[0], first))
+    # one image per cluster size, each in its own compact tiles, + one with member masks: ONE launch
+    arena = msets[0]
+    parts0 = synth.split_by_size(first)
+    isets = [[DeviceBatch(sub, device, tiled=tiled, share_log_with=arena, own_log_off=True)
+              for _, _, _, sub in synth.split_by_size(mb)] for mb in mhost]
+    plans = [eng.plan_rounds(imgs) for imgs in isets]
+    ms = timed_launches(torch, device, lambda i: eng.launch_plan(plans[i % S]), steps, warmup, S)
+    oks = [verify_against_oracle(db, sub) for db, (_, _, _, sub) in zip(isets[0], parts0)]
+    out["mixed_images"] = dict(kernel_ms=ms, frac=frac(bpg, ms), input_sets=S, alg_bytes_per_group=bpg, images=len(parts0),
+                               note=mnote + "; one image per cluster size + one with member masks, rq_plan_rounds (one launch)",
+                               verified=dict(oks[0], ok=all(v["ok"] for v in oks), groups=G,
+                                             mismatched=sorted({m for v in oks for m in v["mismatched"]})))
+    del msets, isets, plans, arena
     torch.cuda.empty_cache()
     # the same workload without the log arena (log_term_start): a looked-up term costs a
     # 128-byte line of its own once logs are hundreds of entries long
-    msets = [DeviceBatch(mb, device, tiled=tiled, term_start=ts) for mb, ts in zip(mhost, mstart)]
+    msets = [DeviceBatch(mb, device, tiled=tiled, term_start=synth.term_start_monotone(mb),
+                         segments=synth.segment_table(mb.old_mask, mb.new_mask)) for mb in mhost]
     ms = timed_launches(torch, device, lambda i: eng.fused_round(msets[i % S]), steps, warmup, S)
     out["mixed_term_start"] = dict(kernel_ms=ms, frac=frac(bpg - 4, ms), input_sets=S, alg_bytes_per_group=bpg - 4,
-                                   note="mixed / joint workload with log_term_start instead of the lookup")
+                                   note="mixed / joint workload (segment table) with log_term_start instead of the lookup")
     del msets
     torch.cuda.empty_cache()
     return out
@@ -538,7 +580,7 @@ def main():
             if args.log_window >= 0:
                 b = synth.window_logs(b, keep_committed=args.log_window)
         else:                                # the 0.9 GB log arena is generated once and shared
-            b = synth.gen_mixed(G, seed=seed, logs_from=first_mixed)
+            b = synth.gen_mixed(G, seed=seed, logs_from=first_mixed, bucketed=True if args.no_segments else "size")
             first_mixed = first_mixed or b
         if args.layout == "i64":
             if args.workload == "mixed" or (ex is not None and args.summary == "i32"):
@@ -553,6 +595,8 @@ def main():
         kw = {}
         if args.workload == "mixed" and sets:
             kw["share_log_with"] = sets[0]
+        if args.workload == "mixed" and not args.no_segments:
+            kw["segments"] = synth.segment_table(b.old_mask, b.new_mask)
         if args.layout == "i32" and args.workload == "fused":
             kw["log_term_bits"] = args.log_term_bits
         tiled = not args.planes and not (ex is not None and args.summary == "i32")   # full vectors land in plain arrays
@@ -706,7 +750,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kernel_ms,
                          "host_enqueue_ms_per_step": (t_enqueued - t0) / args.steps * 1e3,
-                         "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else "rq_round_joint<16,...>"},
+                         "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else ("rq_round_joint<16,...>" if args.no_segments else "rq_round_multi<3,...>")},
             "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
             "verified": verified,
         }

@@ -318,8 +318,10 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  *               explicit summary_base stay plain arrays (rq_groups_scatter_dev /
  *               _gather_dev address either layout).
  *   variant     kernel build: 0 = library default; RQ_VARIANT_PLAIN = default
- *               cache policy instead of non-temporal streaming; bits 8-11 =
- *               threads per block / 64 (1..4).  Never changes results.
+ *               cache policy instead of non-temporal streaming (a diagnostic: only
+ *               libraries built with `make PLAIN=1` contain those kernels, any other
+ *               runs the default build for it); bits 8-11 = threads per block / 64
+ *               (1..4).  Never changes results.
  *   n_segments / seg_first_group / seg_n   a host that keeps groups of DIFFERENT
  *               cluster sizes in one image of n planes orders them by size and
  *               says so here: the groups seg_first_group[s] .. seg_first_group[s+1]

@@ -95,7 +95,7 @@ __device__ __forceinline__ T commit_decision(const rq_round_args_t<T> &r, const 
     st |= (adv && !inb) ? kStLogOob : 0u;
     bool hit = by_start ? nq >= in.ts : false;
     if (!by_start && adv && inb)
-        hit = (T)((U)load_term<true, T>(r.log_term, r.log_term_bits, (size_t)in.beg + (size_t)wi) + (U)in.tb) == in.lt;
+        hit = (T)((U)load_term<T>(r.log_term, r.log_term_bits, (size_t)in.beg + (size_t)wi, true) + (U)in.tb) == in.lt;
     return (adv && inb && hit) ? nq : in.cm;
 }
 
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
         bad |= (uint32_t)(on && !csr) << p;
         tg[p] = 0;
         if (rch && in)
-            tg[p] = (T)((U)load_term<true, T>(a.flog_term, a.flog_term_bits, (size_t)o0[p] + (size_t)wi) + (U)tbase);
+            tg[p] = (T)((U)load_term<T>(a.flog_term, a.flog_term_bits, (size_t)o0[p] + (size_t)wi, true) + (U)tbase);
     }
     // pure outputs live in their own tile block; follower terms updated in place stay with the inputs
     const uint64_t out_tile = a.out_tile_bytes;
@@ -286,10 +286,26 @@ hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, const rq_round
         else if (clamp) RQ_APPEND_LAUNCH(N, false, true);             \
         else RQ_APPEND_LAUNCH(N, false, false);                       \
         break;
-    switch (a.n <= 9 ? a.n : 16u) {
-    RQ_APPEND_CASE(1) RQ_APPEND_CASE(2) RQ_APPEND_CASE(3) RQ_APPEND_CASE(4) RQ_APPEND_CASE(5)
-    RQ_APPEND_CASE(6) RQ_APPEND_CASE(7) RQ_APPEND_CASE(8) RQ_APPEND_CASE(9) RQ_APPEND_CASE(16)
-    default: break;
+    // Builds exist for a subset of slot counts; a batch runs the next larger one (slots beyond
+    // a.n are masked out wave-wide, so they cost a skipped branch, not traffic).  The compact
+    // layout has its own build for the follower counts of 3- to 10-peer clusters that matter
+    // most (1-5, 7, 9); the wide layout, a fallback for values beyond int32, fewer.
+    uint32_t build = 16;
+    if constexpr (sizeof(T) == 4) {
+        for (uint32_t c : {9u, 7u, 5u, 4u, 3u, 2u, 1u}) if (a.n <= c) build = c;
+    } else {
+        for (uint32_t c : {9u, 5u, 4u, 2u}) if (a.n <= c) build = c;
+    }
+    switch (build) {
+    RQ_APPEND_CASE(2) RQ_APPEND_CASE(4) RQ_APPEND_CASE(5) RQ_APPEND_CASE(9) RQ_APPEND_CASE(16)
+    default:
+        if constexpr (sizeof(T) == 4) {
+            switch (build) {
+            RQ_APPEND_CASE(1) RQ_APPEND_CASE(3) RQ_APPEND_CASE(7)
+            default: break;
+            }
+        }
+        break;
     }
 #undef RQ_APPEND_CASE
 #undef RQ_APPEND_LAUNCH

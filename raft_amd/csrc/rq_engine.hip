@@ -379,7 +379,9 @@ int segs_from_desc(const rq_round_desc &d, rq_plan &p) {
         p.segs.n[i] = d.seg_n[i];
     }
     p.segs.first_group[d.n_segments] = d.G;
+#ifdef RQ_BUILD_PLAIN
     if ((d.variant & RQ_VARIANT_PLAIN) && !d.old_mask) return RQ_E_ARG;   // that build decides through the masks
+#endif
     p.segmented = true;
     return RQ_OK;
 }
@@ -1019,6 +1021,8 @@ int rq_plan_rounds(rq_engine *e, const rq_round_desc *descs, uint32_t count, rq_
             d.variant != descs[0].variant || (d.variant & RQ_VARIANT_PLAIN) || one.segmented ||
             (i > 0 && d.start_signal)) { rc = RQ_E_ARG; break; }
         p->image_n[i] = one.n; p->image_joint[i] = one.joint;
+        one.args.nt_gather = rq_nt_gather(one.args);          // per image: each has its own arena
+        one.args64.nt_gather = rq_nt_gather(one.args64);
         if (wide) ((rq_round64_args *)p->many)[i] = one.args64; else ((rq_round_args *)p->many)[i] = one.args;
     }
     if (rc == RQ_OK) {

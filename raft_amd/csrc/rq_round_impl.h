@@ -239,20 +239,21 @@ constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02, kStBadCsr = 0x04;
 // The one dependent, data-indexed load of a round: log[N].TermNum.  Arena
 // entries are `bits` wide -- 8 or 16 (unsigned), 32 (signed) or the full element
 // -- a wave-uniform choice, so the switch is a scalar branch around loads of
-// different widths.  The cache policy is a compile-time choice.
-template <bool NT, typename P>
-__device__ __forceinline__ P load_one(const P *p) {
-    if constexpr (NT) return __builtin_nontemporal_load(p);
-    else return *p;
+// different widths.  Its cache policy (a.nt_gather) is wave-uniform as well.
+template <typename P>
+__device__ __forceinline__ P load_one(const P *p, bool nt) {
+    // two instructions behind a scalar branch: the hint is part of the encoding
+    if (nt) return __builtin_nontemporal_load(p);
+    return *p;
 }
-template <bool NT, typename T>
-__device__ __forceinline__ T load_term(const void *arena, uint32_t bits, size_t idx) {
-    if (bits == 8) return (T)load_one<NT>(static_cast<const uint8_t *>(arena) + idx);
-    if (bits == 16) return (T)load_one<NT>(static_cast<const uint16_t *>(arena) + idx);
+template <typename T>
+__device__ __forceinline__ T load_term(const void *arena, uint32_t bits, size_t idx, bool nt) {
+    if (bits == 8) return (T)load_one(static_cast<const uint8_t *>(arena) + idx, nt);
+    if (bits == 16) return (T)load_one(static_cast<const uint16_t *>(arena) + idx, nt);
     if constexpr (sizeof(T) == 8) {
-        if (bits == 32) return (T)load_one<NT>(static_cast<const int32_t *>(arena) + idx);
+        if (bits == 32) return (T)load_one(static_cast<const int32_t *>(arena) + idx, nt);
     }
-    return load_one<NT>(static_cast<const T *>(arena) + idx);
+    return load_one(static_cast<const T *>(arena) + idx, nt);
 }
 
 // A group's slice [beg, end) of a CSR arena of `total` entries is usable when the
@@ -398,7 +399,7 @@ __device__ __forceinline__ void signal_started(const rq_round_args_t<T> &a) {
 // ---------------------------------------------------------------------------
 // fixed cluster size n = N for every group
 // ---------------------------------------------------------------------------
-template <int N, int V, int WHAT, bool NT, bool NTG, bool FULL, typename T>
+template <int N, int V, int WHAT, bool NT, bool FULL, typename T>
 __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T> &a,
                                                      uint32_t g0, int valid) {
     typedef typename std::make_unsigned<T>::type U;
@@ -479,7 +480,7 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
             gt[k] = 0;
             if (!by_start && adv[k] && inb[k])
-                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
+                gt[k] = (T)((U)load_term<T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi, a.nt_gather != 0) + (U)tb[k]);
         }
     }
 
@@ -536,15 +537,15 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     return round_fields{el_field, nib_field, esc_field, ch_field};
 }
 
-template <int N, int V, int WHAT, bool NT, bool NTG, typename T>
+template <int N, int V, int WHAT, bool NT, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
     signal_started(a);
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     round_fields f{0, 0, 0, 0};
     if (g0 + V <= a.G)
-        f = round_fixed_body<N, V, WHAT, NT, NTG, true>(a, (uint32_t)g0, V);
+        f = round_fixed_body<N, V, WHAT, NT, true>(a, (uint32_t)g0, V);
     else if (g0 < a.G)
-        f = round_fixed_body<N, V, WHAT, NT, NTG, false>(a, (uint32_t)g0, (int)(a.G - g0));
+        f = round_fixed_body<N, V, WHAT, NT, false>(a, (uint32_t)g0, (int)(a.G - g0));
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
         if (a.elected_bits) pack_elected<V>(f.elected, g0, a.G, a.elected_bits);
     }
@@ -604,7 +605,7 @@ __device__ __forceinline__ T masked_quorum(const T (&mt)[MMAX][V], int k, uint32
 // ---------------------------------------------------------------------------
 // LATE_VOTE: the vote side's first chunk of loads is issued after the commit side's
 // sort instead of before it -- fewer loads in flight, a third fewer registers.
-template <int MMAX, int V, int WHAT, bool NT, bool NTG, bool FULL, typename T, bool LATE_VOTE = false>
+template <int MMAX, int V, int WHAT, bool NT, bool FULL, typename T, bool LATE_VOTE = false>
 __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T> &a,
                                                      uint32_t g0, int valid,
                                                      bool in_range) {
@@ -782,7 +783,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
             st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
             gt[k] = 0;
             if (!by_start && adv[k] && inb[k])
-                gt[k] = (T)((U)load_term<NTG, T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi) + (U)tb[k]);
+                gt[k] = (T)((U)load_term<T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi, a.nt_gather != 0) + (U)tb[k]);
         }
     }
 
@@ -833,17 +834,17 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
     return round_fields{el_field, nib_field, esc_field, ch_field};
 }
 
-template <int MMAX, int V, int WHAT, bool NT, bool NTG, typename T>
+template <int MMAX, int V, int WHAT, bool NT, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
     signal_started(a);
     const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
     round_fields f;
     // Every lane runs a body: the wave-wide ballots inside need all of them.
     if (g0 + V <= a.G)
-        f = round_joint_body<MMAX, V, WHAT, NT, NTG, true>(a, (uint32_t)g0, V, true);
+        f = round_joint_body<MMAX, V, WHAT, NT, true>(a, (uint32_t)g0, V, true);
     else {
         const bool in_range = g0 < a.G;
-        f = round_joint_body<MMAX, V, WHAT, NT, NTG, false>(
+        f = round_joint_body<MMAX, V, WHAT, NT, false>(
             a, in_range ? (uint32_t)g0 : 0u, in_range ? (int)(a.G - g0) : 0, in_range);
     }
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
@@ -858,16 +859,16 @@ __global__ __launch_bounds__(kBlock) void rq_round_joint(rq_round_args_t<T> a) {
 }
 
 // ---------------------------------------------------------------------------
-// dispatch.  Builds per kernel family, element type and decision set: the
-// default (every streamed access non-temporal) and RQ_VAR_PLAIN; the log-term
-// gather of the default build is non-temporal only while neighbouring groups
+// dispatch.  One build per kernel family, element type and decision set (every
+// streamed access non-temporal; RQ_BUILD_PLAIN adds the default-policy builds
+// behind RQ_VAR_PLAIN); the log-term
+// gather is non-temporal only while neighbouring groups
 // share arena lines (short logs: the wave's gathers sweep the arena like one
 // more stream, measured 4 % faster at 8-34 bytes of arena per group and 2 %
 // faster at 68 bytes, the int64 arena of the same short logs), and plain
 // when every gather lands in a line of its own (long logs: non-temporal was
 // measured 8-13 % slower at 200 bytes - 3 KB per group).
 // ---------------------------------------------------------------------------
-constexpr uint64_t kNtGatherMaxArenaBytesPerGroup = 128;
 
 template <typename K, typename T>
 hipError_t launch_grid(K kernel, const rq_round_args_t<T> &a, uint32_t block, hipStream_t s) {
@@ -876,40 +877,41 @@ hipError_t launch_grid(K kernel, const rq_round_args_t<T> &a, uint32_t block, hi
     return hipGetLastError();
 }
 
-// policy: 0 = plain, 1 = non-temporal streams + plain gather, 2 = all non-temporal
+// plain: default cache policy for every access (only in builds with RQ_BUILD_PLAIN; a build
+// without them runs the streaming kernels instead -- the policy never changes a result).
 template <int N, int WHAT, typename T>
-hipError_t launch_fixed_policy(const rq_round_args_t<T> &a, int policy, uint32_t block, hipStream_t s) {
-    if (policy == 0) return launch_grid(rq_round_fixed<N, 1, WHAT, false, false, T>, a, block, s);
-    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
-        if (policy == 1) return launch_grid(rq_round_fixed<N, 1, WHAT, true, false, T>, a, block, s);
-    }
-    return launch_grid(rq_round_fixed<N, 1, WHAT, true, true, T>, a, block, s);
+hipError_t launch_fixed_policy(const rq_round_args_t<T> &a, bool plain, uint32_t block, hipStream_t s) {
+#ifdef RQ_BUILD_PLAIN
+    if (plain) return launch_grid(rq_round_fixed<N, 1, WHAT, false, T>, a, block, s);
+#endif
+    (void)plain;
+    return launch_grid(rq_round_fixed<N, 1, WHAT, true, T>, a, block, s);
 }
 
 template <int N, typename T>
-hipError_t launch_fixed_what(const rq_round_args_t<T> &a, int what, int policy, uint32_t block, hipStream_t s) {
+hipError_t launch_fixed_what(const rq_round_args_t<T> &a, int what, bool plain, uint32_t block, hipStream_t s) {
     switch (what) {
-    case RQ_WHAT_COMMIT: return launch_fixed_policy<N, RQ_WHAT_COMMIT>(a, policy, block, s);
-    case RQ_WHAT_VOTE: return launch_fixed_policy<N, RQ_WHAT_VOTE>(a, policy, block, s);
-    default: return launch_fixed_policy<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, policy, block, s);
+    case RQ_WHAT_COMMIT: return launch_fixed_policy<N, RQ_WHAT_COMMIT>(a, plain, block, s);
+    case RQ_WHAT_VOTE: return launch_fixed_policy<N, RQ_WHAT_VOTE>(a, plain, block, s);
+    default: return launch_fixed_policy<N, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, plain, block, s);
     }
 }
 
 template <int MMAX, int WHAT, typename T>
-hipError_t launch_joint_policy(const rq_round_args_t<T> &a, int policy, uint32_t block, hipStream_t s) {
-    if (policy == 0) return launch_grid(rq_round_joint<MMAX, 1, WHAT, false, false, T>, a, block, s);
-    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
-        if (policy == 1) return launch_grid(rq_round_joint<MMAX, 1, WHAT, true, false, T>, a, block, s);
-    }
-    return launch_grid(rq_round_joint<MMAX, 1, WHAT, true, true, T>, a, block, s);
+hipError_t launch_joint_policy(const rq_round_args_t<T> &a, bool plain, uint32_t block, hipStream_t s) {
+#ifdef RQ_BUILD_PLAIN
+    if (plain) return launch_grid(rq_round_joint<MMAX, 1, WHAT, false, T>, a, block, s);
+#endif
+    (void)plain;
+    return launch_grid(rq_round_joint<MMAX, 1, WHAT, true, T>, a, block, s);
 }
 
 template <int MMAX, typename T>
-hipError_t launch_joint_what(const rq_round_args_t<T> &a, int what, int policy, uint32_t block, hipStream_t s) {
+hipError_t launch_joint_what(const rq_round_args_t<T> &a, int what, bool plain, uint32_t block, hipStream_t s) {
     switch (what) {
-    case RQ_WHAT_COMMIT: return launch_joint_policy<MMAX, RQ_WHAT_COMMIT>(a, policy, block, s);
-    case RQ_WHAT_VOTE: return launch_joint_policy<MMAX, RQ_WHAT_VOTE>(a, policy, block, s);
-    default: return launch_joint_policy<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, policy, block, s);
+    case RQ_WHAT_COMMIT: return launch_joint_policy<MMAX, RQ_WHAT_COMMIT>(a, plain, block, s);
+    case RQ_WHAT_VOTE: return launch_joint_policy<MMAX, RQ_WHAT_VOTE>(a, plain, block, s);
+    default: return launch_joint_policy<MMAX, RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a, plain, block, s);
     }
 }
 
@@ -935,7 +937,7 @@ struct multi_subs {
     uint8_t image[RQ_MAX_SEGS];
 };
 
-template <int WHAT, bool NT, bool NTG, typename T>
+template <int WHAT, bool NT, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_multi(rq_round_args_t<T> a0,
                                                          const rq_round_args_t<T> *__restrict__ table,
                                                          multi_subs sb) {
@@ -953,12 +955,12 @@ __global__ __launch_bounds__(kBlock) void rq_round_multi(rq_round_args_t<T> a0,
     const bool in = g < end;
     round_fields f{0, 0, 0, 0};
     switch (kind) {
-#define RQ_SUB_CASE(N) case N: if (in) f = round_fixed_body<N, 1, WHAT, NT, NTG, true>(a, g, 1); break;
+#define RQ_SUB_CASE(N) case N: if (in) f = round_fixed_body<N, 1, WHAT, NT, true>(a, g, 1); break;
     RQ_SUB_CASE(1) RQ_SUB_CASE(2) RQ_SUB_CASE(3) RQ_SUB_CASE(4) RQ_SUB_CASE(5)
     RQ_SUB_CASE(6) RQ_SUB_CASE(7) RQ_SUB_CASE(8) RQ_SUB_CASE(9)
 #undef RQ_SUB_CASE
     default:   // every lane runs the member-mask body: its wave-wide ballots need all of them
-        f = round_joint_body<16, 1, WHAT, NT, NTG, true, T, true>(a, in ? g : 0u, in ? 1 : 0, in);
+        f = round_joint_body<16, 1, WHAT, NT, true, T, true>(a, in ? g : 0u, in ? 1 : 0, in);
     }
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
         if (a.elected_bits) pack_elected<1>(f.elected, g, end, a.elected_bits);
@@ -975,7 +977,7 @@ __global__ __launch_bounds__(kBlock) void rq_round_multi(rq_round_args_t<T> a0,
 // longest get the first blocks -- member masks (one more dependent load), then the fixed
 // sizes from 9 down -- so that the grid drains through its shortest waves.
 template <int WHAT, typename T>
-hipError_t launch_multi(const rq_round_args_t<T> &a0, const rq_round_args_t<T> *table, const multi_subs &in, int policy,
+hipError_t launch_multi(const rq_round_args_t<T> &a0, const rq_round_args_t<T> *table, const multi_subs &in,
                         uint32_t block, hipStream_t s) {
     uint32_t order[RQ_MAX_SEGS];
     for (uint32_t i = 0; i < in.count; i++) order[i] = i;
@@ -995,22 +997,16 @@ hipError_t launch_multi(const rq_round_args_t<T> &a0, const rq_round_args_t<T> *
     for (uint32_t i = sb.count; i <= RQ_MAX_SEGS; i++) sb.first_block[i] = (uint32_t)nb;
     if (nb == 0) return hipSuccess;
     if (nb > 0x7FFFFFFFull) return hipErrorInvalidValue;
-    if constexpr ((WHAT & RQ_WHAT_COMMIT) != 0) {
-        if (policy == 1) {
-            hipLaunchKernelGGL((rq_round_multi<WHAT, true, false, T>), dim3((uint32_t)nb), dim3(block), 0, s, a0, table, sb);
-            return hipGetLastError();
-        }
-    }
-    hipLaunchKernelGGL((rq_round_multi<WHAT, true, true, T>), dim3((uint32_t)nb), dim3(block), 0, s, a0, table, sb);
+    hipLaunchKernelGGL((rq_round_multi<WHAT, true, T>), dim3((uint32_t)nb), dim3(block), 0, s, a0, table, sb);
     return hipGetLastError();
 }
 template <typename T>
 hipError_t launch_multi_what(const rq_round_args_t<T> &a0, const rq_round_args_t<T> *table, const multi_subs &sb,
-                             int what, int policy, uint32_t block, hipStream_t s) {
+                             int what, uint32_t block, hipStream_t s) {
     switch (what) {
-    case RQ_WHAT_COMMIT: return launch_multi<RQ_WHAT_COMMIT>(a0, table, sb, policy, block, s);
-    case RQ_WHAT_VOTE: return launch_multi<RQ_WHAT_VOTE>(a0, table, sb, policy, block, s);
-    default: return launch_multi<RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a0, table, sb, policy, block, s);
+    case RQ_WHAT_COMMIT: return launch_multi<RQ_WHAT_COMMIT>(a0, table, sb, block, s);
+    case RQ_WHAT_VOTE: return launch_multi<RQ_WHAT_VOTE>(a0, table, sb, block, s);
+    default: return launch_multi<RQ_WHAT_COMMIT | RQ_WHAT_VOTE>(a0, table, sb, block, s);
     }
 }
 
@@ -1048,21 +1044,23 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if (bsel > 4) return hipErrorInvalidValue;
     const bool fixed = !joint && n >= 1 && n <= 9;
     const uint32_t block = bsel ? 64u * (uint32_t)bsel : (uint32_t)(fixed ? kDefaultBlockFixed : kDefaultBlockJoint);
-    int policy = 2;
-    if (variant & RQ_VAR_PLAIN) policy = 0;
-    else if ((what & RQ_WHAT_COMMIT) &&
-             args.log_terms * (tb / 8) > kNtGatherMaxArenaBytesPerGroup * (uint64_t)args.G) policy = 1;
+    bool plain = false;
+#ifdef RQ_BUILD_PLAIN
+    plain = (variant & RQ_VAR_PLAIN) != 0;
+#endif
+    rq_round_args_t<T> a = args;
+    a.nt_gather = rq_nt_gather(args);
     if (segs) {
         // Groups ordered by size in an image of n planes; member masks are needed only by
         // segments of kind 0 (without masks those take all n slots as their one configuration).
-        rq_round_args_t<T> b = args;
+        rq_round_args_t<T> b = a;
         b.m = n;
         if (!joint) { b.old_mask = nullptr; b.new_mask = nullptr; }
         if (n < 1 || n > 16 || !segs_ok(*segs, b.G, n)) return hipErrorInvalidValue;
         if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
         // The table never changes a result, only which code decides a group: the plain
         // cache policy has no segmented build and decides every group through its masks.
-        if (policy != 0) {
+        if (!plain) {
             multi_subs sb;
             std::memset(&sb, 0, sizeof sb);
             sb.count = segs->count;
@@ -1071,23 +1069,22 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
                 sb.end_group[i] = segs->first_group[i + 1];
                 sb.kind[i] = segs->n[i];
             }
-            return launch_multi_what<T>(b, nullptr, sb, what, policy, bsel ? block : (uint32_t)kDefaultBlockFixed, stream);
+            return launch_multi_what<T>(b, nullptr, sb, what, bsel ? block : (uint32_t)kDefaultBlockFixed, stream);
         }
         if (!joint) return hipErrorInvalidValue;
     }
-    const rq_round_args_t<T> &a = args;
 
     if (fixed && !segs) {
         switch (n) {
-        case 1: return launch_fixed_what<1>(a, what, policy, block, stream);
-        case 2: return launch_fixed_what<2>(a, what, policy, block, stream);
-        case 3: return launch_fixed_what<3>(a, what, policy, block, stream);
-        case 4: return launch_fixed_what<4>(a, what, policy, block, stream);
-        case 5: return launch_fixed_what<5>(a, what, policy, block, stream);
-        case 6: return launch_fixed_what<6>(a, what, policy, block, stream);
-        case 7: return launch_fixed_what<7>(a, what, policy, block, stream);
-        case 8: return launch_fixed_what<8>(a, what, policy, block, stream);
-        default: return launch_fixed_what<9>(a, what, policy, block, stream);
+        case 1: return launch_fixed_what<1>(a, what, plain, block, stream);
+        case 2: return launch_fixed_what<2>(a, what, plain, block, stream);
+        case 3: return launch_fixed_what<3>(a, what, plain, block, stream);
+        case 4: return launch_fixed_what<4>(a, what, plain, block, stream);
+        case 5: return launch_fixed_what<5>(a, what, plain, block, stream);
+        case 6: return launch_fixed_what<6>(a, what, plain, block, stream);
+        case 7: return launch_fixed_what<7>(a, what, plain, block, stream);
+        case 8: return launch_fixed_what<8>(a, what, plain, block, stream);
+        default: return launch_fixed_what<9>(a, what, plain, block, stream);
         }
     }
     // per-group membership, or a fixed size beyond the register networks
@@ -1095,8 +1092,8 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     if (!joint) { b.m = n; b.old_mask = nullptr; b.new_mask = nullptr; }
     if (b.m < 1 || b.m > 16) return hipErrorInvalidValue;
     if ((b.old_mask == nullptr) != (b.new_mask == nullptr)) return hipErrorInvalidValue;
-    if (b.m <= 8) return launch_joint_what<8>(b, what, policy, block, stream);
-    return launch_joint_what<16>(b, what, policy, block, stream);
+    if (b.m <= 8) return launch_joint_what<8>(b, what, plain, block, stream);
+    return launch_joint_what<16>(b, what, plain, block, stream);
 }
 
 // Several images in one grid.  args[i] / n[i] / joint[i]: image i as rq_launch_round takes it;
@@ -1111,7 +1108,6 @@ hipError_t launch_rounds_impl(const rq_round_args_t<T> *args, const uint32_t *n,
     multi_subs sb;
     std::memset(&sb, 0, sizeof sb);
     sb.count = count;
-    uint64_t arena_bytes = 0, groups = 0;
     for (uint32_t i = 0; i < count; i++) {
         const rq_round_args_t<T> &a = args[i];
         if (a.G > 0x7FFFFFFFu || (a.ld < a.G && !a.tile_bytes)) return hipErrorInvalidValue;
@@ -1120,11 +1116,8 @@ hipError_t launch_rounds_impl(const rq_round_args_t<T> *args, const uint32_t *n,
         sb.first_group[i] = 0; sb.end_group[i] = a.G;
         sb.kind[i] = fixed ? (uint8_t)n[i] : 0;
         sb.image[i] = (uint8_t)i;
-        arena_bytes += a.log_terms * (a.log_term_bits / 8);
-        groups += a.G;
     }
-    const int policy = ((what & RQ_WHAT_COMMIT) && arena_bytes > kNtGatherMaxArenaBytesPerGroup * groups) ? 1 : 2;
-    return launch_multi_what<T>(args[0], table, sb, what, policy, bsel ? 64u * (uint32_t)bsel : (uint32_t)kDefaultBlockFixed, stream);
+    return launch_multi_what<T>(args[0], table, sb, what, bsel ? 64u * (uint32_t)bsel : (uint32_t)kDefaultBlockFixed, stream);
 }
 
 }  // namespace
