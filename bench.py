@@ -131,14 +131,82 @@ def parse():
     ap.add_argument("--preheat-rotations", type=int, default=32,
                     help="untimed passes over all input sets before --warmup (the first builds every "
                          "prepared launch and touches every buffer)")
+    ap.add_argument("--strong-total", type=int, default=8388608,
+                    help="2 or 4 ranks: total groups of the additional strong-scaling figure (extra.strong_8m)")
+    ap.add_argument("--watchdog-seconds", type=float, default=60.0,
+                    help="a rank that retires no step for this long dumps its stacks and exits with code 3 (0 = off)")
+    ap.add_argument("--launcher-timeout", type=float, default=540.0,
+                    help="--gpus N without a launcher: give up, and kill every rank, after this many seconds")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "hbm_traffic.json"))
     return ap.parse_args()
+
+
+def supervise(procs, deadline_s, out=None):
+    """Wait for the rank processes `procs` (each started in a session of its own).  Rank 0's
+    stdout (a pipe) is collected; the first rank that exits non-zero, or the deadline, ends the
+    run: every rank still alive is killed with its whole process group, so no rank is left
+    holding a GPU inside a collective whose peer is gone.  Returns (exit code, rank 0's stdout)."""
+    import signal
+    import threading
+    chunks = []
+    reader = None
+    if procs[0].stdout is not None:
+        reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+
+    def kill_all():
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    p.kill()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+
+    def on_term(signum, frame):
+        kill_all()
+        os._exit(128 + signum)
+
+    old = {}
+    if threading.current_thread() is threading.main_thread():
+        for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+            old[sig] = signal.signal(sig, on_term)
+    rc, why = 0, None
+    t_end = time.monotonic() + deadline_s
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                rc, why = 1, "rank(s) failed: %s" % bad
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.monotonic() > t_end:
+                rc, why = 1, "no result after %.0f s; ranks still running: %s" % (
+                    deadline_s, [r for r, c in enumerate(codes) if c is None])
+                break
+            time.sleep(0.05)
+    finally:
+        kill_all()
+        for sig, h in old.items():
+            signal.signal(sig, h)
+    if reader is not None:
+        reader.join(timeout=5)
+    if why:
+        (out or sys.stderr).write("bench.py: %s\n" % why)
+    return rc, b"".join(c for c in chunks if c)
 
 
 def launch_ranks(args):
     """--gpus N without a launcher: this process (which has not touched torch or the
     GPU) starts the N ranks as children with the rendezvous in their environment,
-    relays rank 0's JSON line and exits non-zero if any rank does."""
+    relays rank 0's JSON line and exits non-zero if any rank does (the other ranks are
+    killed at once) or when --launcher-timeout runs out."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -147,23 +215,67 @@ def launch_ranks(args):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         out = subprocess.PIPE if r == 0 else sys.stderr
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out))
-    line, _ = procs[0].communicate()
-    codes = []
-    deadline = time.time() + 120            # the other ranks end with rank 0; do not wait for a wedged one
-    for p in procs:
-        try:
-            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
-        except subprocess.TimeoutExpired:
-            p.kill()
-            codes.append(p.wait())
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: rank(s) failed: %s\n" % bad)
-        sys.exit(1)
-    sys.stdout.write(line.decode())
-    sys.stdout.flush()
-    sys.exit(0)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out,
+                                      start_new_session=True))
+    rc, line = supervise(procs, args.launcher_timeout)
+    if rc == 0:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    sys.exit(rc)
+
+
+class Watchdog:
+    """Per-rank progress watchdog.  While armed, beat() must be called at least every `limit_s`
+    seconds (every step and every fence stage does); otherwise the rank writes what it was
+    doing -- the Python stacks of all threads and the exchange's host-side state -- to stderr
+    and leaves with exit code 3, which makes the launcher end the other ranks: a wedged fence
+    or collective then costs a minute and leaves a diagnosis instead of running into the
+    caller's time limit with nothing."""
+
+    def __init__(self, limit_s, describe=None, out=None, exit_fn=None):
+        import threading
+        self.limit_s, self.describe = float(limit_s), describe
+        self.out = out or sys.stderr
+        self.exit_fn = exit_fn or (lambda code: os._exit(code))
+        self.armed, self.last, self.where, self.beats = False, time.monotonic(), "start", 0
+        self.fired = False
+        if self.limit_s > 0:
+            threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, where):
+        self.last, self.where = time.monotonic(), where
+        self.beats += 1
+
+    def arm(self, where):
+        self.beat(where)
+        self.armed = True
+
+    def disarm(self):
+        self.armed = False
+
+    def _run(self):
+        import faulthandler
+        while not self.fired:
+            time.sleep(min(1.0, self.limit_s / 4))
+            idle = time.monotonic() - self.last
+            if self.armed and idle > self.limit_s:
+                self.fired = True
+                self.out.write("bench.py watchdog: rank %s made no progress for %.0f s (last: %s, %d beats)\n" % (
+                    os.environ.get("RANK", "0"), idle, self.where, self.beats))
+                if self.describe is not None:
+                    try:
+                        self.out.write("bench.py watchdog: %s\n" % json.dumps(self.describe(), default=str))
+                    except Exception as e:          # the diagnosis must not stop the exit
+                        self.out.write("bench.py watchdog: state unavailable: %r\n" % (e,))
+                self.out.flush()
+                try:
+                    faulthandler.dump_traceback(file=self.out, all_threads=True)
+                except Exception:                   # not a real file (no descriptor): format the stacks here
+                    import traceback
+                    for tid, frame in sys._current_frames().items():
+                        self.out.write("Thread 0x%x:\n%s" % (tid, "".join(traceback.format_stack(frame))))
+                self.out.flush()
+                self.exit_fn(3)
 
 
 def cpu_baseline(args, synth):
@@ -550,6 +662,171 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
+    if args.summary == "auto":
+        args.summary = "u8" if args.workload == "fused" else "u16"
+    eng = DeviceEngine(dev_index)
+    exchange = use_dist and not args.no_exchange
+    state = {}                                   # what the watchdog reports
+    dog = Watchdog(args.watchdog_seconds, lambda: dict(
+        step=state.get("step"), phase=state.get("phase"), exchange=state["ex"].debug_state() if state.get("ex") else None))
+    hang_rank, hang_step = (int(x) for x in os.environ.get("RQ_BENCH_INJECT_HANG", "-1:-1").split(":"))
+
+    def measure(G, S, steps, warmup, preheat_rotations, label):
+        """Build S rotating input/output sets of G groups on this rank, run the untimed rotations,
+        then time `steps` steps with the exchange (if any) and -- with more than one rank or a forced
+        exchange -- the same steps again without it, so that one invocation separates the kernels'
+        scaling from the cost of the exchange."""
+        n = args.peers
+        R = max(1, min(args.rounds_per_exchange, S))
+        while S % R:
+            R -= 1                                   # every input set maps to one (slot, round-in-slot)
+        depth = S // R
+        ex = SummaryExchange(G, device, depth=depth, mode=args.summary, impl=args.exchange_impl,
+                             rounds=R, fence=args.fence) if exchange else None
+        state["ex"] = ex
+        consumer = SummaryConsumer(ex) if (ex is not None and args.consume) else None
+        # one run-long counter of groups whose commit offset left the 16-bit summary window
+        escape_counter = torch.zeros(2, dtype=torch.int32, device=device) if ex is not None else None
+        sets, first_mixed, host_batches, verify_host = [], None, [], None
+        for s in range(S):
+            seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
+            if args.workload == "fused":
+                b = synth.gen_fused(G, n, seed=seed, ld=G + args.ld_pad)
+                if args.log_window >= 0:
+                    b = synth.window_logs(b, keep_committed=args.log_window)
+            else:                                # the 0.9 GB log arena is generated once and shared
+                b = synth.gen_mixed(G, seed=seed, logs_from=first_mixed, bucketed=True if args.no_segments else "size")
+                first_mixed = first_mixed or b
+            if args.layout == "i64":
+                if args.workload == "mixed" or (ex is not None and args.summary == "i32"):
+                    raise SystemExit("--layout i64 runs the fused workload with a narrow (u4, u8, u16) summary")
+                # indices can only leave the int32 range together with a window base
+                b, _ = synth.widen(b, index_shift=(1 << 40) if args.log_window >= 0 else 0,
+                                   term_shift=1 << 41, id_shift=1 << 42, seed=seed)
+            elif args.workload == "fused":
+                host_batches.append(b)
+            if s == 0:
+                verify_host = b                  # what set 0's outputs are checked against after the timed region
+            kw = {}
+            if args.workload == "mixed" and sets:
+                kw["share_log_with"] = sets[0]
+            if args.workload == "mixed" and not args.no_segments:
+                kw["segments"] = synth.segment_table(b.old_mask, b.new_mask)
+            if args.layout == "i32" and args.workload == "fused":
+                kw["log_term_bits"] = args.log_term_bits
+            tiled = not args.planes and not (ex is not None and args.summary == "i32")   # full vectors land in plain arrays
+            if tiled:
+                kw["tiled"] = True
+            if ex is not None and args.summary == "i32":
+                kw.update(commit_out=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R))
+            elif ex is not None:
+                kw.update(commit_lo16=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R),
+                          summary_escapes=escape_counter, summary_bits=ex.bits,
+                          summary_base="commit" if ex.bits < 16 else None)
+            if ex is not None and s % R == 0:
+                # the first round of a slot releases the exchange of the slot before it
+                kw["start_signal"] = ex.start_signal((s // R - 1) % depth)   # None with event fences
+            sets.append(DeviceBatch(b, device, **kw))
+        if args.workload == "fused":
+            bytes_per_group = alg_bytes_per_group(n, args.what, args.layout)
+            workload = "%d groups x %d peers per GPU, fused RequestVote tally + commitIndex advance with log-term gather" % (G, n)
+        else:
+            om = b.old_mask.astype("int64"); nm = b.new_mask.astype("int64")
+            members = sum(((om | nm) >> p) & 1 for p in range(16)).mean()
+            bytes_per_group = 20 * members + 37 + 4          # member slots only + two u16 masks
+            workload = "%d groups, mixed 3-9 peers + 10%% joint consensus, Zipf log lengths" % G
+
+        debug = bool(os.environ.get("RQ_BENCH_DEBUG"))
+
+        def step(i, with_ex=True):
+            s = i % S
+            x = ex if with_ex else None
+            state["step"] = i
+            dog.beat("step")
+            if debug:
+                sys.stderr.write("rank %d step %d\n" % (rank, i)); sys.stderr.flush()
+            if rank == hang_rank and i == hang_step and state.get("phase") == label + ":timed":
+                time.sleep(1e6)                  # test hook: this rank never gets to its next collective
+            if x is not None and s % R == 0:
+                x.begin(s // R)                  # the slot's previous all-gather must be done
+            if args.what == "fused":
+                eng.fused_round(sets[s], variant=args.variant, want_bits=not args.no_bits, status=not args.no_status)
+            elif args.what == "commit":
+                eng.commit_advance(sets[s], variant=args.variant)
+            else:
+                eng.vote_tally(sets[s], variant=args.variant)
+            if x is not None and s % R == 0:
+                x.round_started((s // R - 1) % depth)
+            if x is not None and s % R == R - 1:
+                x.filled(s // R)                     # R rounds of summaries in one collective
+                if consumer is not None:
+                    # device-side decode of the PREVIOUS exchange: its all-gather has had a whole
+                    # exchange period to finish, so the compute stream does not stall on it
+                    consumer.consume((s // R - 1) % depth)
+
+        def fence(with_ex=True):
+            dog.beat("fence: exchange")
+            if ex is not None and with_ex:
+                ex.wait_all()
+            dog.beat("fence: device")
+            torch.cuda.synchronize(device)
+            dog.beat("fence: barrier")
+            if use_dist:
+                dist.barrier()
+            torch.cuda.synchronize(device)
+            dog.beat("fence: done")
+
+        def timed(with_ex):
+            """`warmup` untimed and `steps` timed steps between fences: (host seconds, kernel ms per step,
+            host seconds spent enqueuing)."""
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev0.record(); ev1.record()                # creates the events outside the timed region
+            state["phase"] = label + ":warmup"
+            for i in range(warmup):
+                step(i, with_ex)
+            fence(with_ex)
+            state["phase"] = label + ":timed"
+            t0 = time.perf_counter()
+            ev0.record()
+            for i in range(steps):
+                step(i, with_ex)
+            ev1.record()                              # same stream as the kernels
+            t_enqueued = time.perf_counter()
+            if ex is not None and with_ex:
+                ex.wait_all()
+            eng.stream_sync()                         # polls the kernels' stream: a blocked thread wakes 10-20 us late
+            t1 = time.perf_counter()
+            fence(with_ex)
+            return t1 - t0, ev0.elapsed_time(ev1) / steps, t_enqueued - t0
+
+        # untimed: build every set's prepared launch and touch every buffer once
+        dog.arm(label + ":preheat")
+        state["phase"] = label + ":preheat"
+        preheat = S * max(1, preheat_rotations)
+        for i in range(preheat):
+            step(i)
+        fence()
+        wall, kernel_ms, enq = timed(True)
+        res = dict(G=G, S=S, R=R, ex=ex, consumer=consumer, sets=sets, host_batches=host_batches, verify_host=verify_host,
+                   bytes_per_group=bytes_per_group, workload=workload, preheat=preheat, wall=wall, kernel_ms=kernel_ms,
+                   enqueue_s=enq, escape_counter=escape_counter, compute_only=None)
+        if ex is not None:
+            # the same steps without the exchange: the launches still write their summaries into
+            # the exchange's buffers, nothing is sent (the exchange is not used again afterwards)
+            cw, ck, _ = timed(False)
+            res["compute_only"] = dict(wall=cw, kernel_ms=ck)
+        dog.disarm()
+        state["phase"] = label + ":done"
+        return res
+
+    def over_ranks(x, op):
+        if not use_dist:
+            return float(x)
+        tt = torch.tensor([x], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=op)
+        return float(tt.item())
+
     strong = args.total_groups > 0
     if strong:
         from raft_amd.sharded import shard_bounds
@@ -557,136 +834,28 @@ def main():
             raise SystemExit("--total-groups must be a multiple of the number of ranks")
         g0, g1 = shard_bounds(args.total_groups, world, rank)
         args.groups = g1 - g0
-    if args.summary == "auto":
-        args.summary = "u8" if args.workload == "fused" else "u16"
     G, n, S = args.groups, args.peers, max(1, args.sets)
-    eng = DeviceEngine(dev_index)
-    exchange = use_dist and not args.no_exchange
-    R = max(1, min(args.rounds_per_exchange, S))
-    while S % R:
-        R -= 1                                   # every input set maps to one (slot, round-in-slot)
-    depth = S // R
-    ex = SummaryExchange(G, device, depth=depth, mode=args.summary, impl=args.exchange_impl,
-                         rounds=R, fence=args.fence) if exchange else None
-    consumer = SummaryConsumer(ex) if (ex is not None and args.consume) else None
-
-    # one run-long counter of groups whose commit offset left the 16-bit summary window
-    escape_counter = torch.zeros(2, dtype=torch.int32, device=device) if ex is not None else None
-    sets, first_mixed, host_batches, verify_host = [], None, [], None
-    for s in range(S):
-        seed = synth.DEFAULT_SEED + 7919 * rank + 104729 * s
-        if args.workload == "fused":
-            b = synth.gen_fused(G, n, seed=seed, ld=G + args.ld_pad)
-            if args.log_window >= 0:
-                b = synth.window_logs(b, keep_committed=args.log_window)
-        else:                                # the 0.9 GB log arena is generated once and shared
-            b = synth.gen_mixed(G, seed=seed, logs_from=first_mixed, bucketed=True if args.no_segments else "size")
-            first_mixed = first_mixed or b
-        if args.layout == "i64":
-            if args.workload == "mixed" or (ex is not None and args.summary == "i32"):
-                raise SystemExit("--layout i64 runs the fused workload with a narrow (u4, u8, u16) summary")
-            # indices can only leave the int32 range together with a window base
-            b, _ = synth.widen(b, index_shift=(1 << 40) if args.log_window >= 0 else 0,
-                               term_shift=1 << 41, id_shift=1 << 42, seed=seed)
-        elif args.workload == "fused":
-            host_batches.append(b)
-        if s == 0:
-            verify_host = b                  # what set 0's outputs are checked against after the timed region
-        kw = {}
-        if args.workload == "mixed" and sets:
-            kw["share_log_with"] = sets[0]
-        if args.workload == "mixed" and not args.no_segments:
-            kw["segments"] = synth.segment_table(b.old_mask, b.new_mask)
-        if args.layout == "i32" and args.workload == "fused":
-            kw["log_term_bits"] = args.log_term_bits
-        tiled = not args.planes and not (ex is not None and args.summary == "i32")   # full vectors land in plain arrays
-        if tiled:
-            kw["tiled"] = True
-        if ex is not None and args.summary == "i32":
-            kw.update(commit_out=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R))
-        elif ex is not None:
-            kw.update(commit_lo16=ex.commit_view(s // R, s % R), elected_bits=ex.bits_view(s // R, s % R),
-                      summary_escapes=escape_counter, summary_bits=ex.bits,
-                      summary_base="commit" if ex.bits < 16 else None)
-        if ex is not None and s % R == 0:
-            # the first round of a slot releases the exchange of the slot before it
-            kw["start_signal"] = ex.start_signal((s // R - 1) % depth)   # None with event fences
-        sets.append(DeviceBatch(b, device, **kw))
+    m = measure(G, S, args.steps, args.warmup, args.preheat_rotations, "main")
+    ex, consumer, sets, host_batches, verify_host = m["ex"], m["consumer"], m["sets"], m["host_batches"], m["verify_host"]
+    R, preheat, bytes_per_group, workload = m["R"], m["preheat"], m["bytes_per_group"], m["workload"]
+    escape_counter = m["escape_counter"]
     log_term_bits = sets[0].log_term_bits
-    if args.workload == "fused":
-        bytes_per_group = alg_bytes_per_group(n, args.what, args.layout)
-        workload = "%d groups x %d peers per GPU, fused RequestVote tally + commitIndex advance with log-term gather" % (G, n)
-    else:
-        om = b.old_mask.astype("int64"); nm = b.new_mask.astype("int64")
-        members = sum(((om | nm) >> p) & 1 for p in range(16)).mean()
-        bytes_per_group = 20 * members + 37 + 4          # member slots only + two u16 masks
-        workload = "%d groups, mixed 3-9 peers + 10%% joint consensus, Zipf log lengths" % G
     resident_mb = sum(x.bytes_resident() for x in sets) / 1e6
-
-    debug = bool(os.environ.get("RQ_BENCH_DEBUG"))
-
-    def step(i):
-        s = i % S
-        if debug:
-            sys.stderr.write("rank %d step %d\n" % (rank, i)); sys.stderr.flush()
-        if ex is not None and s % R == 0:
-            ex.begin(s // R)                 # the slot's previous all-gather must be done
-        if args.what == "fused":
-            eng.fused_round(sets[s], variant=args.variant, want_bits=not args.no_bits, status=not args.no_status)
-        elif args.what == "commit":
-            eng.commit_advance(sets[s], variant=args.variant)
-        else:
-            eng.vote_tally(sets[s], variant=args.variant)
-        if ex is not None and s % R == 0:
-            ex.round_started((s // R - 1) % depth)
-        if ex is not None and s % R == R - 1:
-            ex.filled(s // R)                    # R rounds of summaries in one collective
-            if consumer is not None:
-                # device-side decode of the PREVIOUS exchange: its all-gather has had a whole
-                # exchange period to finish, so the compute stream does not stall on it
-                consumer.consume((s // R - 1) % depth)
-
-    def fence():
-        if ex is not None:
-            ex.wait_all()
-        torch.cuda.synchronize(device)
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
-    # untimed: build every set's prepared launch and touch every buffer once
-    preheat = S * max(1, args.preheat_rotations)
-    for i in range(preheat):
-        step(i)
-    fence()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    ev0.record(); ev1.record()                # creates the events outside the timed region
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        step(i)
-    ev1.record()                              # same stream as the kernels
-    t_enqueued = time.perf_counter()
-    if ex is not None:
-        ex.wait_all()
-    eng.stream_sync()                         # polls the kernels' stream: a blocked thread wakes 10-20 us late
-    t1 = time.perf_counter()
-    torch.cuda.synchronize(device)
+    kernel_ms, t_enqueue_s = m["kernel_ms"], m["enqueue_s"]
+    wall = over_ranks(m["wall"], dist.ReduceOp.MAX) if use_dist else m["wall"]
+    kernel_ms_ranks = None
+    compute_only = None
     if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    wall = t1 - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps   # avg launch duration on the kernel's stream
+        kernel_ms_ranks = dict(max=over_ranks(kernel_ms, dist.ReduceOp.MAX), min=over_ranks(kernel_ms, dist.ReduceOp.MIN))
+        if m["compute_only"] is not None:
+            cw = over_ranks(m["compute_only"]["wall"], dist.ReduceOp.MAX)
+            ck = m["compute_only"]["kernel_ms"]
+            compute_only = dict(ms_per_step=cw / args.steps * 1e3, value=G * world * args.steps / cw,
+                                kernel_ms=dict(max=over_ranks(ck, dist.ReduceOp.MAX), min=over_ranks(ck, dist.ReduceOp.MIN)),
+                                note="the same steps without the summary exchange (max over ranks of the host clock)")
 
     devices = [dev_index]
     if use_dist:
-        tt = torch.tensor([wall], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall = float(tt.item())
         ids = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(world)]
         dist.all_gather(ids, torch.tensor([dev_index], dtype=torch.int64, device=device))
         devices = [int(t.item()) for t in ids]
@@ -706,60 +875,95 @@ def main():
     summary_escapes = None
     if ex is not None:      # the 16-bit window must have held on this rank for the whole run
         summary_escapes = int(escape_counter[0].item())
+    total_groups = G * world
+    value = total_groups * args.steps / wall
+    achieved = bytes_per_group * G / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_source = None, None
+    try:
+        tj = json.load(open(args.traffic_json))
+        key = "%s%s_G%d_n%d" % (args.workload, "_i64" if args.layout == "i64" else "", G, n)
+        ent = tj.get(key)
+        if ent is not None:
+            if ent.get("kernel_source_hash") == kernel_source_hash():
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_source = "rocprofv3 --pmc profile %s of kernel %s (not measured by this run)" % (
+                    ent.get("source"), ent.get("kernel"))
+            else:
+                traffic_source = "none: the kernel source changed since profile %s was taken" % ent.get("source")
+    except (OSError, ValueError):
+        pass
+    line = {
+        "metric": "quorum decisions/sec at 1M groups x 5 peers (1/8 GPU); % of HBM peak",
+        "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "int64" if args.layout == "i64" else "int32", "data": "synthetic",
+        "config": {"workload": workload, "groups_per_gpu": G, "total_groups": total_groups,
+                   "scaling_note": ("strong scaling: %d groups block-partitioned over %d ranks" % (total_groups, world)) if strong
+                   else ("weak scaling: %d groups on every GPU; BASELINE's sharded configuration is 8388608 groups in "
+                         "total (strong), the same workload as this one only at 8 GPUs" % G),
+                   "peers": n, "input_sets": S,
+                   "preheat_rounds": preheat,
+                   "resident_mb_per_gpu": round(resident_mb, 1),
+                   "rccl_ranks": dist.get_world_size() if use_dist else 1,
+                   "backend": args.backend if use_dist else None, "devices": devices,
+                   "summary_allgather": bool(exchange),
+                   "summary_bytes_per_rank": ex.nbytes if ex is not None else 0,
+                   "summary_mode": args.summary if ex is not None else None,
+                   "summary_impl": ex.impl if ex is not None else None,
+                   "summary_consumed_on_device": consumer is not None,
+                   "rounds_per_allgather": R if ex is not None else None,
+                   "exchange_fence": ex.fence if ex is not None else None,
+                   "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what,
+                   "ld_pad": args.ld_pad, "log_window": args.log_window, "layout": args.layout,
+                   "log_term_bits": log_term_bits, "tiled": bool(getattr(sets[0], "tile_bytes", 0)),
+                   "alg_bytes_per_group": bytes_per_group},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "kernel_ms": kernel_ms,
+                     "host_enqueue_ms_per_step": t_enqueue_s / args.steps * 1e3,
+                     "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else ("rq_round_joint<16,...>" if args.no_segments else "rq_round_multi<3,...>")},
+        "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
+        "verified": verified,
+    }
+    if use_dist:
+        line["roofline"]["kernel_ms_ranks"] = kernel_ms_ranks
+        line.setdefault("extra", {})
+        if compute_only is not None:
+            line["extra"]["compute_only"] = compute_only
+    # 2 or 4 ranks: the sharded configuration itself (8M groups in total, block-partitioned) beside
+    # the weak-scaling headline, every rank taking part
+    if world in (2, 4) and not strong and args.workload == "fused" and not args.no_extras:
+        del sets, host_batches, verify_host
+        m["sets"] = m["host_batches"] = m["verify_host"] = None
+        if consumer is not None:
+            consumer.close()
+        if ex is not None:
+            ex.close()
+        ex = consumer = m["ex"] = m["consumer"] = None
+        torch.cuda.empty_cache()
+        total8 = args.strong_total
+        m8 = measure(total8 // world, 4, args.steps, args.warmup, 2, "strong_8m")
+        w8 = over_ranks(m8["wall"], dist.ReduceOp.MAX)
+        v8 = verify_against_oracle(m8["sets"][0], m8["verify_host"], what=3)
+        ok8 = over_ranks(1.0 if v8["ok"] else 0.0, dist.ReduceOp.MIN) == 1.0
+        line["extra"]["strong_8m"] = dict(
+            total_groups=total8, groups_per_gpu=total8 // world, ms_per_step=w8 / args.steps * 1e3,
+            value=total8 * args.steps / w8, kernel_ms=dict(max=over_ranks(m8["kernel_ms"], dist.ReduceOp.MAX),
+                                                           min=over_ranks(m8["kernel_ms"], dist.ReduceOp.MIN)),
+            input_sets=4, verified=dict(v8, ok=ok8),
+            compute_only_ms_per_step=None if m8["compute_only"] is None else
+            over_ranks(m8["compute_only"]["wall"], dist.ReduceOp.MAX) / args.steps * 1e3,
+            note="BASELINE's sharded configuration: %d groups x %d peers block-partitioned over the ranks (strong scaling)" % (total8, n))
+        failed = failed or not ok8
+        sets, ex, consumer = m8["sets"], m8["ex"], m8["consumer"]
     if rank == 0:
-        total_groups = G * world
-        value = total_groups * args.steps / wall
-        achieved = bytes_per_group * G / (kernel_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        try:
-            tj = json.load(open(args.traffic_json))
-            key = "%s%s_G%d_n%d" % (args.workload, "_i64" if args.layout == "i64" else "", G, n)
-            ent = tj.get(key)
-            if ent is not None:
-                if ent.get("kernel_source_hash") == kernel_source_hash():
-                    traffic = ent.get("hbm_bytes_per_launch")
-                    traffic_source = "rocprofv3 --pmc profile %s of kernel %s (not measured by this run)" % (
-                        ent.get("source"), ent.get("kernel"))
-                else:
-                    traffic_source = "none: the kernel source changed since profile %s was taken" % ent.get("source")
-        except (OSError, ValueError):
-            pass
-        line = {
-            "metric": "quorum decisions/sec at 1M groups x 5 peers (1/8 GPU); % of HBM peak",
-            "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "int64" if args.layout == "i64" else "int32", "data": "synthetic",
-            "config": {"workload": workload, "groups_per_gpu": G, "peers": n, "input_sets": S,
-                       "preheat_rounds": preheat,
-                       "resident_mb_per_gpu": round(resident_mb, 1),
-                       "rccl_ranks": dist.get_world_size() if use_dist else 1,
-                       "backend": args.backend if use_dist else None, "devices": devices,
-                       "summary_allgather": bool(exchange),
-                       "summary_bytes_per_rank": ex.nbytes if ex is not None else 0,
-                       "summary_mode": args.summary if ex is not None else None,
-                       "summary_impl": ex.impl if ex is not None else None,
-                       "summary_consumed_on_device": consumer is not None,
-                       "rounds_per_allgather": R if ex is not None else None,
-                       "exchange_fence": ex.fence if ex is not None else None,
-                       "summary_escapes": summary_escapes, "variant": args.variant, "what": args.what,
-                       "ld_pad": args.ld_pad, "log_window": args.log_window, "layout": args.layout,
-                       "log_term_bits": log_term_bits, "tiled": bool(getattr(sets[0], "tile_bytes", 0)),
-                       "alg_bytes_per_group": bytes_per_group},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": kernel_ms,
-                         "host_enqueue_ms_per_step": (t_enqueued - t0) / args.steps * 1e3,
-                         "kernel": "rq_round_fixed<%d,...>" % n if args.workload == "fused" else ("rq_round_joint<16,...>" if args.no_segments else "rq_round_multi<3,...>")},
-            "pct_hbm_peak": 100.0 * achieved / HBM_PEAK_GBS,
-            "verified": verified,
-        }
         plain = world == 1 and args.workload == "fused" and args.layout == "i32" and args.what == "fused"
         if plain and not args.no_extras:
             del sets
             torch.cuda.empty_cache()
             # a failure in a secondary figure must not cost the line: what was measured so far stays
-            line["extra"] = {}
+            line.setdefault("extra", {})
             try:
                 extras(args, torch, synth, DeviceBatch, eng, device, host_batches, line["extra"])
             except Exception as e:

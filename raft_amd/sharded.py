@@ -184,6 +184,17 @@ class SummaryExchange:
             self._l.rq_engine_destroy(self._eng)
             self._eng = None
 
+    def debug_state(self):
+        """Host-side bookkeeping of every slot, for a diagnosis when a run is stuck (no device
+        access: the device may be what is stuck)."""
+        st = dict(impl=self.impl, fence=self.fence, world=self.world, rank=self.rank, rounds=self.rounds,
+                  message_bytes=self.nbytes, filled=list(self._filled))
+        if self.fence == "signal":
+            st["launched_with_signal"] = list(self._launched)
+        if self._cuda and self._comm is None:
+            st["exchange_pending"] = list(self._pending)
+        return st
+
     def start_signal(self, slot):
         """fence="signal": address of the slot's signal word, for the descriptor of the
         launch that follows the slot's last round; None with event fences."""
