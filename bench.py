@@ -590,7 +590,7 @@ def extras(args, torch, synth, DeviceBatch, eng, device, host_batches, out):
                         verified=verify_against_oracle(msets[0], first))
     # the same images decided through the member masks alone (no table): what every group cost before
     for db in msets:
-        db.segments, db._args = None, {}
+        db.segments = None
     ms = timed_launches(torch, device, lambda i: eng.fused_round(msets[i % S]), steps, warmup, S)
     out["mixed_masks_only"] = dict(kernel_ms=ms, frac=frac(bpg, ms), input_sets=S, alg_bytes_per_group=bpg,
                                    note=mnote + "; every group decided through its member masks",

@@ -229,7 +229,11 @@ void BatchedDriver::ApplyT(std::vector<Group> &groups, const RoundBuffersT<T> &b
                     grp.Candidate = nullptr;
                 }
             }
+            // the round decided the commit rule for the leader the group had when it ran
             if (leader_before) leader_before->commitIndex = b.commitOut[g];
+            // a leader a vote request demoted (raft.go:221) leads no more: later rounds must not
+            // advance commitIndex for a Follower
+            if (grp.Leader && grp.Leader->nodeType != Leader) grp.Leader = nullptr;
         }
     });
 }

@@ -324,6 +324,12 @@ void ResidentDriver::ApplyRow(uint32_t g, const T *row, uint64_t flags) {
         }
     }
     if (leader_before) leader_before->commitIndex = row[0];
+    // a leader a vote request demoted (raft.go:221) leads no more: its row goes up again
+    // without leader arrays, so that later rounds do not advance commitIndex for a Follower
+    if (grp.Leader && grp.Leader->nodeType != Leader) {
+        grp.Leader = nullptr;
+        MarkDirty(g);
+    }
     if (status) flagged_.push_back(GroupStatus{g, status});
 }
 
@@ -354,16 +360,26 @@ int ResidentDriver::StepT(Report *report) {
         T *rows = (T *)(I.h_in + (((uint64_t)r * 2 + 1) * 4 + 7) / 8 * 8), *rterms = rows + (size_t)r * words;
         std::vector<T> terms;
         uint64_t used = 0;
+        // Slices that move to free arena space are booked at once (later rows of this batch must
+        // not get the same space) and taken back if the batch does not go up after all: a row
+        // that cannot be flattened, or a rebuild, must leave the bookkeeping as the device has it.
+        struct Moved { uint32_t g, off, cap; };
+        std::vector<Moved> moved;
+        const uint64_t tail_before = I.tail;
+        auto take_back = [&]() {
+            for (auto it = moved.rbegin(); it != moved.rend(); ++it) { I.off[it->g] = it->off; I.cap[it->g] = it->cap; }
+            I.tail = tail_before;
+        };
         for (uint32_t i = 0; i < r && !need_rebuild; i++) {
             const uint32_t g = dirty_[i];
             T *row = rows + (size_t)i * words;
             LogShape shape;
-            RH_TRY(FlattenRow<T>(g, row, terms, I.by_start ? &shape : nullptr));
+            if (const int frc = FlattenRow<T>(g, row, terms, I.by_start ? &shape : nullptr)) { take_back(); return frc; }
             if (!mixed_ && groups_[g].Members.size() != n) { need_rebuild = true; break; }
             if (I.by_start) {
                 // a log that lost Raft's shape needs the arena back: everything is laid out afresh
                 if (!shape.shaped) { need_rebuild = true; break; }
-                if (!narrow(shape.term_start, row[4 * n + 6])) return RQ_E_RANGE;
+                if (!narrow(shape.term_start, row[4 * n + 6])) { take_back(); return RQ_E_RANGE; }
                 gids[i] = g;
                 roff[i] = (uint32_t)used;            // lengths only: no terms travel
                 used += shape.len;
@@ -375,6 +391,7 @@ int ResidentDriver::StepT(Report *report) {
                 // when that runs out everything is laid out afresh
                 const uint64_t want = 2 * (uint64_t)terms.size() + 4;
                 if (I.tail + want > I.arena_entries) { need_rebuild = true; break; }
+                moved.push_back(Moved{g, I.off[g], I.cap[g]});
                 I.off[g] = (uint32_t)I.tail;
                 I.cap[g] = (uint32_t)want;
                 I.tail += want;
@@ -386,14 +403,16 @@ int ResidentDriver::StepT(Report *report) {
             std::memcpy(rterms + used, terms.data(), terms.size() * E);
             used += terms.size();
         }
+        if (need_rebuild) take_back();
         if (!need_rebuild) {
             roff[r] = (uint32_t)used;
             const uint64_t bytes = (uint64_t)((const char *)rterms - I.h_in) + (I.by_start ? 0 : used) * E;
-            RH_TRY(rq_copy_to_device(I.e, I.d_in, I.h_in, bytes));
+            if (const int crc = rq_copy_to_device(I.e, I.d_in, I.h_in, bytes)) { take_back(); return crc; }
             const char *d = I.d_in;
-            RH_TRY(rq_groups_scatter_dev(I.e, nullptr, &I.desc, r, (const uint32_t *)d,
-                                         d + ((const char *)rows - I.h_in), (const uint32_t *)(d + ((const char *)roff - I.h_in)),
-                                         d + ((const char *)rterms - I.h_in), nullptr));
+            const int src = rq_groups_scatter_dev(I.e, nullptr, &I.desc, r, (const uint32_t *)d,
+                                                  d + ((const char *)rows - I.h_in), (const uint32_t *)(d + ((const char *)roff - I.h_in)),
+                                                  d + ((const char *)rterms - I.h_in), nullptr);
+            if (src) { take_back(); return src; }
             rep.uploaded = r;
             for (uint32_t g : dirty_) dirty_mark_[g] = 0;
             dirty_.clear();

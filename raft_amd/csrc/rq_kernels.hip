@@ -39,8 +39,11 @@ hipError_t rq_launch_groups_gather(const rq_round_args &a, uint32_t n, uint32_t 
 // ---------------------------------------------------------------------------
 // Summary consumer (sharded deployment): every rank keeps a replica of every
 // rank's commitIndex and adds the gathered per-round advances to it.  One thread
-// per (rank, group); offsets of 16 / 8 / 4 bits, all ones = escape (left alone,
-// counted with one atomic per wave).
+// per (rank, group); offsets of 16 / 8 / 4 bits, all ones = escape: the advance of
+// that round is unknown, so nothing of the message is added for the group from
+// that round on (the replica entry stays exact up to the round before, and the
+// host, which sees the count, fetches the full vectors of the period); escapes
+// are counted with one atomic per wave.
 // ---------------------------------------------------------------------------
 namespace {
 __global__ __launch_bounds__(256) void rq_summary_apply_kernel(const uint8_t *msg, uint64_t msg_stride,
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256) void rq_summary_apply_kernel(const uint8_t *ms
             if (bits == 16) v = reinterpret_cast<const uint16_t *>(sec)[g];
             else if (bits == 8) v = sec[g];
             else v = (sec[g >> 1] >> (4 * (g & 1))) & 0xFu;   // little-endian words: group g in bits 4*(g%16)
-            if (v == escape) esc++;
-            else sum += v;
+            if (v == escape) { esc++; break; }       // later rounds build on an advance this message does not carry
+            sum += v;
         }
         if (sum) replica[(uint64_t)r * groups + g] += (int32_t)sum;
     }
@@ -75,7 +78,7 @@ hipError_t rq_launch_summary_apply(const uint8_t *msg, uint64_t msg_stride, uint
                                    int32_t *replica, uint32_t *escapes, hipStream_t stream) {
     if (ranks == 0 || groups == 0 || rounds == 0) return hipSuccess;
     if ((bits != 16 && bits != 8 && bits != 4) || ranks > 65535u) return hipErrorInvalidValue;
-    if (bits == 16 && ((section_off | msg_stride | round_stride) & 1u)) return hipErrorInvalidValue;
+    if (bits == 16 && ((section_off | msg_stride | round_stride | reinterpret_cast<uintptr_t>(msg)) & 1u)) return hipErrorInvalidValue;
     const dim3 grid((groups + 255u) / 256u, ranks), blk(256);
     hipLaunchKernelGGL(rq_summary_apply_kernel, grid, blk, 0, stream, msg, msg_stride, section_off, round_stride,
                        rounds, groups, bits, replica, escapes);

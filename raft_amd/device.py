@@ -511,7 +511,13 @@ class DeviceEngine:
         """Enqueue the commit (what & 1) and/or vote (what & 2) decision for DeviceBatch b
         on torch's current stream.  The descriptor is validated once into an rq_plan
         per (batch, options); every later call is a two-argument rq_plan_launch."""
-        key = (what, variant, want_bits, status)
+        # everything the descriptor bakes in besides the batch's own arrays: a field reassigned
+        # after the first launch (a signal word, a summary buffer) gets a plan of its own
+        o = b.o
+        addr = lambda x: None if x is None else x.data_ptr()
+        key = (what, variant, want_bits, status, b.start_signal, addr(o.get("changed_bits")), addr(o.get("commit_lo16")),
+               addr(o.get("summary_escapes")), addr(b.summary_base), b.summary_bits, addr(o.get("elected_bits")),
+               addr(o.get("commit_out")), None if b.segments is None else (tuple(b.segments[0]), tuple(b.segments[1])))
         plan = b._args.get(key)
         if plan is None:
             d = self.describe(b, what, variant, want_bits, status)

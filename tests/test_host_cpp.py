@@ -147,7 +147,10 @@ def test_flatten_matches_the_objects_and_apply_matches_the_oracle():
                 assert new_lead == cand and new_cand == -1
                 assert c.get(g, cand)["nodeType"] == h.LEADER and c.leader_arrays(g, cand) is not None
             else:
-                assert new_lead == lead and new_cand == cand
+                # a leader the candidate's term demoted (raft.go:221) leads no more
+                demoted = (r.stepdown_mask[g] >> lead) & 1
+                assert new_lead == (-1 if demoted else lead) and new_cand == cand
+                assert c.get(g, lead)["nodeType"] == (h.FOLLOWER if demoted else h.LEADER)
     finally:
         c.close()
 
@@ -172,7 +175,8 @@ def test_flatten_and_apply_on_several_threads():
                 assert c.get(g, p)["currentTerm"] == r.voter_term[p, g]
             assert c.get(g, lead)["commitIndex"] == r.commit[g]
             new_lead, new_cand = c.get_roles(g)
-            assert (new_lead, new_cand) == ((cand, -1) if r.elected[g] else (lead, cand))
+            demoted = (r.stepdown_mask[g] >> lead) & 1
+            assert (new_lead, new_cand) == ((cand, -1) if r.elected[g] else (-1 if demoted else lead, cand))
     finally:
         c.close()
 
