@@ -881,7 +881,8 @@ def main():
     traffic, traffic_source = None, None
     try:
         tj = json.load(open(args.traffic_json))
-        key = "%s%s_G%d_n%d" % (args.workload, "_i64" if args.layout == "i64" else "", G, n)
+        key = "%s%s%s_G%d_n%d" % (args.workload, "_masks" if (args.workload == "mixed" and args.no_segments) else "",
+                                  "_i64" if args.layout == "i64" else "", G, n)
         ent = tj.get(key)
         if ent is not None:
             if ent.get("kernel_source_hash") == kernel_source_hash():

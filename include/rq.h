@@ -26,6 +26,40 @@
  * caller (goroutine) may arrive on any OS thread.
  *
  * No CPU fallback exists: without a usable GPU rq_engine_create fails.
+ *
+ * Threading.  The host-buffer entry points (rq_fused_round, rq_commit_advance,
+ * rq_vote_tally, their _joint forms, rq_round64, rq_append_check(64),
+ * rq_follower_clamp(64), rq_upload / rq_step / rq_download) take the engine's
+ * mutex, use its stream and return when the results are in the caller's
+ * buffers: any number of threads may share an engine, the calls are serialised.
+ * The device-pointer calls take NO lock and touch no engine state beyond the
+ * device number and the last-error word: rq_round_dev, rq_append_check_dev,
+ * rq_groups_scatter_dev, rq_groups_gather_dev, rq_summary_apply_dev,
+ * rq_plan_round(s), rq_plan_launch, rq_stream_wait_signal, rq_stream_sync,
+ * rq_device_alloc / _free, rq_host_alloc / _free, rq_copy_to / _from_device.
+ * They only enqueue on the stream they are given (the copies and rq_stream_sync
+ * block the calling thread), so they may run concurrently with each other and
+ * with the host-buffer calls, from any threads, on the same engine.  What the
+ * caller must not do: destroy a plan, an engine or a communicator while another
+ * thread is inside a call that uses it; free or overwrite device buffers that a
+ * launch still in flight reads or writes (ordering between launches is the
+ * stream's: two launches on one stream run in order, on two streams they may
+ * overlap); launch two rounds that update the same image in place on different
+ * streams.  A plan is immutable after rq_plan_round(s) and may be launched from
+ * several threads at once.  rq_last_hip_error is the last failure of any thread.
+ *
+ * Stability.  STABLE (kept source- and binary-compatible within a major
+ * version; descriptors grow only at their end and older struct_size values stay
+ * accepted): the engine lifetime calls, every host-buffer entry point,
+ * rq_round_dev / rq_plan_round / rq_plan_launch / rq_plan_destroy with
+ * rq_round_desc, rq_append_check_dev with rq_append_desc, rq_groups_scatter_dev /
+ * _gather_dev, rq_stream_sync, the memory calls with RQ_MEM_DEFAULT,
+ * rq_fused_round_noalloc, the status bits and return codes.  EXPERIMENTAL (may
+ * change shape between minor versions as the multi-GPU path is measured on real
+ * nodes): start signals (rq_round_desc.start_signal, rq_stream_wait_signal,
+ * RQ_MEM_SIGNAL), the rq_comm_* communicator, rq_summary_apply_dev and the narrow
+ * commit summary fields, rq_plan_rounds, the segment table, the RQ_MEM_FINEGRAINED
+ * / RQ_MEM_UNCACHED kinds and the `variant` bits.
  */
 #ifndef RQ_H
 #define RQ_H

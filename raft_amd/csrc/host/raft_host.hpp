@@ -217,6 +217,9 @@ public:
     // log_term_start).  A log that loses the shape (the reference appends whatever it is
     // sent, raft.go:158-170) makes the next Step lay the image out afresh with an arena.
     bool WithoutArena() const;
+    // segments of the launch's size table: non-zero when the groups differ in size and are kept in
+    // size order, so that tiles of one size are decided by the fixed-size code
+    uint32_t Segments() const;
     bool Wide() const { return wide_; }      // the image holds int64 elements
     std::vector<Group> &Groups() { return groups_; }
 

@@ -231,6 +231,7 @@ int rh_resident_step(rh_cluster *c, uint32_t *report) {
     return rc;
 }
 int rh_resident_without_arena(rh_cluster *c) { return c->resident && c->resident->WithoutArena() ? 1 : 0; }
+int rh_resident_segments(rh_cluster *c) { return c->resident ? (int)c->resident->Segments() : 0; }
 int rh_resident_wide(rh_cluster *c) { return c->resident && c->resident->Wide() ? 1 : 0; }
 uint32_t rh_resident_flagged(rh_cluster *c, uint32_t *groups, uint8_t *status, uint32_t cap) {
     const std::vector<GroupStatus> &f = c->resident->Flagged();

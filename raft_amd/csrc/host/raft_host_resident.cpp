@@ -48,6 +48,9 @@ struct ResidentDriver::Impl {
     char *d_in = nullptr, *d_out = nullptr, *h_in = nullptr, *h_out = nullptr;
     uint64_t *h_cbits = nullptr;
     bool by_start = false;              // no arena: log_term_start + log_len
+    // groups of different sizes kept in size order: the launch's segment table, and per 64-group
+    // tile the cluster size all of its groups have (0: decided through the member masks)
+    std::vector<uint8_t> tile_kind;
 
     int dalloc(uint64_t bytes, void **out) {
         int rc = rq_device_alloc(e, bytes ? bytes : 4, RQ_MEM_DEFAULT, out);
@@ -108,6 +111,7 @@ ResidentDriver::LogShape ResidentDriver::ShapeOf(uint32_t g) const {
 }
 
 bool ResidentDriver::WithoutArena() const { return impl_ && impl_->plan && impl_->by_start; }
+uint32_t ResidentDriver::Segments() const { return impl_ && impl_->plan ? impl_->desc.n_segments : 0; }
 
 // `shape` non-null: the image keeps no arena -- the log is only measured (ShapeOf), its
 // terms are not copied and `terms` stays empty.
@@ -271,9 +275,36 @@ int ResidentDriver::RebuildT() {
         RH_TRY(rq_copy_to_device(I.e, arena_dev, arena.data(), (uint64_t)arena.size() * E));
         d.log_term = arena_dev;
     }
+    I.tile_kind.clear();
     if (mixed_) {
         d.old_mask = (const uint16_t *)(in_dev + o_om);
         d.new_mask = (const uint16_t *)(in_dev + o_nm);
+        // A host that keeps its groups in size order gets the fixed-size code for every tile whose
+        // groups agree on their size (rq_round_desc.n_segments); any other order, or more runs than
+        // the table holds, and every group is decided through its masks as before.
+        const uint32_t tiles = (G + 63) / 64;
+        std::vector<uint8_t> kind(tiles, 0);
+        for (uint32_t t = 0; t < tiles; t++) {
+            const size_t k0 = groups_[(size_t)t * 64].Members.size();
+            bool same = k0 >= 1 && k0 <= 9;
+            for (uint32_t g = t * 64 + 1; same && g < G && g < (t + 1) * 64; g++) same = groups_[g].Members.size() == k0;
+            kind[t] = same ? (uint8_t)k0 : 0;
+        }
+        uint32_t runs = 1;
+        for (uint32_t t = 1; t < tiles; t++) runs += kind[t] != kind[t - 1];
+        if (runs <= RQ_MAX_SEGMENTS) {
+            uint32_t sidx = 0;
+            for (uint32_t t = 0; t < tiles; t++) {
+                if (t == 0 || kind[t] != kind[t - 1]) {
+                    d.seg_first_group[sidx] = t * 64;
+                    d.seg_n[sidx] = kind[t];
+                    sidx++;
+                }
+            }
+            d.seg_first_group[sidx] = G;
+            d.n_segments = sidx;
+            I.tile_kind = std::move(kind);
+        }
     }
     // state is updated in place between rounds, as the host applies it to its Nodes
     d.commit_out = const_cast<void *>(d.commit);
@@ -376,6 +407,10 @@ int ResidentDriver::StepT(Report *report) {
             LogShape shape;
             if (const int frc = FlattenRow<T>(g, row, terms, I.by_start ? &shape : nullptr)) { take_back(); return frc; }
             if (!mixed_ && groups_[g].Members.size() != n) { need_rebuild = true; break; }
+            // a group that left the size its segment was launched under: the table is made afresh
+            if (!I.tile_kind.empty() && I.tile_kind[g >> 6] && groups_[g].Members.size() != I.tile_kind[g >> 6]) {
+                need_rebuild = true; break;
+            }
             if (I.by_start) {
                 // a log that lost Raft's shape needs the arena back: everything is laid out afresh
                 if (!shape.shaped) { need_rebuild = true; break; }

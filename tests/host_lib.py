@@ -58,6 +58,7 @@ def lib():
         l.rh_resident_mark_dirty.argtypes = [C.c_void_p, C.c_uint32]; l.rh_resident_mark_dirty.restype = None
         l.rh_resident_step.argtypes = [C.c_void_p, u32p]
         l.rh_resident_without_arena.argtypes = [C.c_void_p]
+        l.rh_resident_segments.argtypes = [C.c_void_p]
         l.rh_resident_wide.argtypes = [C.c_void_p]
         l.rh_resident_flagged.argtypes = [C.c_void_p, u32p, u8p, C.c_uint32]
         l.rh_resident_flagged.restype = C.c_uint32
@@ -101,6 +102,10 @@ class Cluster:
         rep = (C.c_uint32 * 3)()
         rc = self.l.rh_resident_step(self.h, rep)
         return rc, dict(uploaded=rep[0], changed=rep[1], rebuilt=bool(rep[2]))
+
+    def segments(self):
+        """Segments of the resident launch's size table (0: none)."""
+        return int(self.l.rh_resident_segments(self.h))
 
     def without_arena(self):
         """True while the resident image keeps no log arena (log_term_start + log_len)."""

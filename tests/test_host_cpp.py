@@ -548,6 +548,54 @@ def test_resident_driver_tracks_the_oracle_over_incremental_steps():
 
 
 @pytest.mark.gpu
+def test_resident_driver_with_groups_of_different_sizes_in_size_order():
+    """3..9-member groups resident on the device.  Kept in size order the driver launches with the
+    size table (tiles of one size run the fixed-size code); a group that changes its size is a
+    rebuild.  The objects end up where the oracle's member-mask round on a fresh flatten puts them."""
+    G = 3000
+    c, b, sizes = _build_mixed(G, seed=12)
+    assert (np.diff(sizes.astype(np.int64)) >= 0).all()              # gen_mixed without joint groups is in size order
+    rng = np.random.default_rng(4)
+    try:
+        c.use_resident(0)
+        for g in range(G):
+            c.roles(g, *c.get_roles(g))
+        for it in range(3):
+            if it:
+                for g in rng.choice(G, 200, replace=False).tolist():
+                    lead, cand = c.get_roles(g)
+                    k = int(sizes[g])
+                    if lead >= 0:
+                        s = c.get(g, lead)
+                        c.set_match(g, lead, [int(x) for x in rng.integers(0, max(1, s["logLen"]), k)])
+                    if cand >= 0:
+                        s = c.get(g, cand)
+                        c.seed(g, cand, s["currentTerm"] + 1, s["votedFor"], h.CANDIDATE, s["commitIndex"])
+            rc, f = c.flatten(log_cap=1 << 23)
+            assert rc == 0 and f["mixed"]
+            exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                                f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"],
+                                old_mask=f["member_mask"], new_mask=f["member_mask"])
+            roles_before = [c.get_roles(g) for g in range(G)]
+            rc, rep = c.step_resident()
+            assert rc == 0 and rep["rebuilt"] == (it == 0)
+            assert 7 <= c.segments() <= 16                             # sizes 3..9 + the tiles where two sizes meet
+            for g in range(G):
+                lead, cand = roles_before[g]
+                if cand >= 0:
+                    for p in range(int(sizes[g])):
+                        assert c.get(g, p)["currentTerm"] == exp.voter_term[p, g], (it, g, p)
+                    assert (c.get_roles(g)[0] == cand) == bool(exp.elected[g]), (it, g)
+                if lead >= 0:
+                    assert c.get(g, lead)["commitIndex"] == exp.commit[g], (it, g)
+            for g in range(G):
+                lead, cand = c.get_roles(g)
+                c.l.rh_group_roles(c.h, g, lead, cand)
+    finally:
+        c.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("wide", [False, True])
 def test_resident_driver_random_schedule(wide):
     """(wide: every term beyond 2^40, so the image is laid out in int64 elements from the first step.)

@@ -136,25 +136,50 @@ for arena, bits, tiled in (("int32 log-term arena, planes", None, False), ("8-bi
 del hosts
 torch.cuda.empty_cache()
 
-# C5: 1M mixed 3-9 + joint, Zipf logs (arena shared between the sets)
-first = synth.gen_mixed(G, seed=500)
-sets = [DeviceBatch(first, dev)]
-for s in range(1, 8):
-    sets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), dev, share_log_with=sets[0]))
-mem = (first.old_mask | first.new_mask).astype(np.int64)
-members = float(sum((mem >> p) & 1 for p in range(16)).mean())
-sec = timed(lambda i: eng.fused_round(sets[i % 8]), 200, 20)
-out.append(rate("C5 1M mixed 3-9 peers + 10% joint, Zipf logs, int32 log-term arena", G, 20 * members + 41, sec,
-                dict(mean_member_slots=members, arena_entries=int(first.log_term.size))))
-del sets
-torch.cuda.empty_cache()
-sets = [DeviceBatch(first, dev, log_term_bits=0)]
-for s in range(1, 8):
-    sets.append(DeviceBatch(synth.gen_mixed(G, seed=500 + s, logs_from=first), dev, share_log_with=sets[0]))
-sec = timed(lambda i: eng.fused_round(sets[i % 8]), 200, 20)
-out.append(rate("C5 1M mixed 3-9 peers + 10% joint, Zipf logs, 8-bit log-term arena entries", G, 20 * members + 41, sec,
-                dict(mean_member_slots=members, arena_entries=int(first.log_term.size))))
-del sets
+# C5: 1M mixed 3-9 + joint, Zipf logs (arena shared between the sets): every group through its
+# member masks (groups ordered by highest slot), then ordered by cluster size and launched with
+# the segment table, then one image per size in ONE launch; tiles throughout
+mem = members = None
+for order, label in ((True, "ordered by highest slot, every group through its member masks"),
+                     ("size", "ordered by cluster size, segment table"),
+                     ("images", "one image per cluster size + one with member masks, one launch (rq_plan_rounds)")):
+    for bits, arena in ((None, "int32 log-term arena"), (0, "8-bit log-term arena entries")):
+        first = synth.gen_mixed(G, seed=500, bucketed=True if order is True else "size")
+        hosts = [first] + [synth.gen_mixed(G, seed=500 + s, bucketed=True if order is True else "size", logs_from=first)
+                           for s in range(1, 8)]
+        mem = (first.old_mask | first.new_mask).astype(np.int64)
+        members = float(sum((mem >> p) & 1 for p in range(16)).mean())
+        kw = {} if bits is None else dict(log_term_bits=bits)
+        if order == "images":
+            arena_owner = DeviceBatch(first, dev, tiled=True, **kw)
+            isets = [[DeviceBatch(sub, dev, tiled=True, share_log_with=arena_owner, own_log_off=True)
+                      for _, _, _, sub in synth.split_by_size(hb)] for hb in hosts]
+            plans = [eng.plan_rounds(imgs) for imgs in isets]
+            sec = timed(lambda i: eng.launch_plan(plans[i % 8]), 200, 20)
+            del isets, plans, arena_owner
+        else:
+            sets = []
+            for hb in hosts:
+                sets.append(DeviceBatch(hb, dev, tiled=True, share_log_with=sets[0] if sets else None,
+                                        segments=synth.segment_table(hb.old_mask, hb.new_mask) if order == "size" else None,
+                                        **({} if sets else kw)))
+            sec = timed(lambda i: eng.fused_round(sets[i % 8]), 200, 20)
+            del sets
+        out.append(rate("C5 1M mixed 3-9 peers + 10%% joint, Zipf logs, %s; %s" % (arena, label), G, 20 * members + 41, sec,
+                        dict(mean_member_slots=members, arena_entries=int(first.log_term.size))))
+        del hosts, first
+        torch.cuda.empty_cache()
+
+# C3 again: k of the 1M x 5 batches decided by ONE grid (rq_plan_rounds)
+hosts = [synth.gen_fused(G, 5, seed=3000 + s, ld=G + 256) for s in range(12)]
+sets = [DeviceBatch(b, dev, log_term_bits=0, tiled=True) for b in hosts]
+for k in (2, 4, 6):
+    plans = [eng.plan_rounds([sets[(j * k + i) % 12] for i in range(k)]) for j in range(12 // k)]
+    sec = timed(lambda i: eng.launch_plan(plans[i % len(plans)]), 120, 12)
+    out.append(rate("C3 1M x 5 fused round, %d batches per launch (rq_plan_rounds), 8-bit arena entries, tiles; per batch" % k,
+                    G, 137, sec / k, dict(batches_per_launch=k, us_per_grid=sec * 1e6)))
+    del plans
+del sets, hosts
 torch.cuda.empty_cache()
 
 # AppendEntries consistency batch: 1M groups, 4 followers each
