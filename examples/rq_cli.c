@@ -8,6 +8,11 @@
  *   rq_cli host      rq_fused_round on host buffers
  *   rq_cli device    rq_device_alloc + rq_copy_to_device + rq_round_dev on
  *                    the default stream + rq_stream_sync + rq_copy_from_device
+ *   rq_cli segmented the device path for groups of DIFFERENT sizes kept in size order: two more
+ *                    input lines (old_mask[G], new_mask[G]); the program works out the size
+ *                    table itself (rq_round_desc.n_segments) and launches once
+ *   rq_cli rounds    the same input cut into two images at a 64-group boundary, decided by
+ *                    ONE launch through rq_plan_rounds / rq_plan_launch
  *   rq_cli replicate one AppendEntries batch through rq_append_check_dev with the
  *                    follower commit rule and the leader's commit round in the same
  *                    launch (its own input format, see replicate())
@@ -151,7 +156,9 @@ static int replicate(void) {
 
 int main(int argc, char **argv) {
     if (argc > 1 && strcmp(argv[1], "replicate") == 0) return replicate();
-    const int device_mode = argc > 1 && strcmp(argv[1], "device") == 0;
+    const int segmented = argc > 1 && strcmp(argv[1], "segmented") == 0;
+    const int rounds = argc > 1 && strcmp(argv[1], "rounds") == 0;
+    const int device_mode = segmented || rounds || (argc > 1 && strcmp(argv[1], "device") == 0);
     rq_engine *e = NULL;
     long long G_in, n_in;
     if (scanf("%lld %lld", &G_in, &n_in) != 2 || G_in < 1 || n_in < 1 || n_in > RQ_MAX_SLOTS) {
@@ -166,6 +173,13 @@ int main(int argc, char **argv) {
     int32_t *log_term = read_i32(arena);
     int32_t *voter_term = read_i32(plane), *voted_for = read_i32(plane), *last_log_term = read_i32(plane);
     int32_t *cand_term = read_i32(G), *cand_id = read_i32(G);
+    uint16_t *old_mask = NULL, *new_mask = NULL;
+    if (segmented || rounds) {
+        int32_t *om = read_i32(G), *nm = read_i32(G);
+        old_mask = (uint16_t *)calloc(G, 2); new_mask = (uint16_t *)calloc(G, 2);
+        for (uint32_t g = 0; g < G; g++) { old_mask[g] = (uint16_t)om[g]; new_mask[g] = (uint16_t)nm[g]; }
+        free(om); free(nm);
+    }
 
     int32_t *commit_out = (int32_t *)calloc(G, 4), *voter_term_out = (int32_t *)calloc(plane, 4);
     int32_t *max_term = (int32_t *)calloc(G, 4);
@@ -212,7 +226,67 @@ int main(int argc, char **argv) {
         d.commit_out = d_co; d.voter_term_out = d_vto;
         d.grant_mask = (uint16_t *)d_gm; d.stepdown_mask = (uint16_t *)d_sm; d.elected = (uint8_t *)d_el;
         d.max_term = d_mx; d.status_out = (uint8_t *)d_st;
-        CHECK(rq_round_dev(e, NULL, &d));
+        void *d_om = NULL, *d_nm = NULL;
+        if (old_mask) {
+            CHECK(to_device(e, old_mask, (size_t)G * 2, &d_om));
+            CHECK(to_device(e, new_mask, (size_t)G * 2, &d_nm));
+            d.old_mask = (const uint16_t *)d_om; d.new_mask = (const uint16_t *)d_nm;
+        }
+        if (segmented) {
+            /* a 64-group tile whose groups are all plain clusters of one size k (old == new ==
+             * the k lowest slots) belongs to a segment of kind k; any other tile to one of kind
+             * 0, decided through the masks; neighbouring tiles of one kind share a segment */
+            uint32_t count = 0, prev = 99;
+            for (uint32_t t = 0; t * 64 < G; t++) {
+                uint32_t kind = 0;
+                for (uint32_t g = t * 64; g < G && g < (t + 1) * 64; g++) {
+                    uint32_t k = 0;
+                    for (uint32_t c = 1; c <= 9; c++)
+                        if (old_mask[g] == new_mask[g] && old_mask[g] == (1u << c) - 1u) k = c;
+                    if (g == t * 64) kind = k;
+                    else if (k != kind) kind = 0;
+                    if (!k) kind = 0;
+                }
+                if (kind != prev) {
+                    if (count == RQ_MAX_SEGMENTS) { fprintf(stderr, "rq_cli: groups are not in size order\n"); return 2; }
+                    d.seg_first_group[count] = t * 64;
+                    d.seg_n[count] = (uint8_t)kind;
+                    count++;
+                    prev = kind;
+                }
+            }
+            d.seg_first_group[count] = G;
+            d.n_segments = count;
+            fprintf(stderr, "rq_cli: %u segments\n", count);
+        }
+        if (rounds) {
+            /* two images of one state: the second starts `mid` groups into every array */
+            const uint32_t mid = (G / 2) & ~63u;
+            rq_round_desc two[2];
+            two[0] = d; two[1] = d;
+            uint32_t images = 1;
+            if (mid) {
+                images = 2;
+                two[0].G = mid; two[1].G = G - mid;
+#define SHIFT(field, type) two[1].field = (type *)two[1].field + mid
+                SHIFT(match, const int32_t); SHIFT(commit, const int32_t); SHIFT(leader_term, const int32_t);
+                SHIFT(log_off, const uint32_t);
+                SHIFT(voter_term, const int32_t); SHIFT(voted_for, const int32_t); SHIFT(voter_last_log_term, const int32_t);
+                SHIFT(cand_term, const int32_t); SHIFT(cand_id, const int32_t);
+                SHIFT(old_mask, const uint16_t); SHIFT(new_mask, const uint16_t);
+                SHIFT(commit_out, int32_t); SHIFT(voter_term_out, int32_t); SHIFT(max_term, int32_t);
+                SHIFT(grant_mask, uint16_t); SHIFT(stepdown_mask, uint16_t);
+                SHIFT(elected, uint8_t); SHIFT(status_out, uint8_t);
+#undef SHIFT
+            }
+            rq_plan *plan = NULL;
+            CHECK(rq_plan_rounds(e, two, images, &plan));
+            CHECK(rq_plan_launch(plan, NULL));
+            CHECK(rq_stream_sync(e, NULL));
+            CHECK(rq_plan_destroy(plan));
+        } else {
+            CHECK(rq_round_dev(e, NULL, &d));
+        }
         CHECK(rq_stream_sync(e, NULL));
         CHECK(rq_copy_from_device(e, commit_out, d_co, (size_t)G * 4));
         CHECK(rq_copy_from_device(e, voter_term_out, d_vto, plane * 4));
@@ -224,6 +298,8 @@ int main(int argc, char **argv) {
         void *all[] = {d_match, d_commit, d_lt, d_off, d_log, d_vt, d_vf, d_ll, d_ct, d_ci,
                        d_co, d_vto, d_gm, d_sm, d_el, d_mx, d_st};
         for (size_t i = 0; i < sizeof all / sizeof all[0]; i++) CHECK(rq_device_free(e, all[i]));
+        CHECK(rq_device_free(e, d_om));
+        CHECK(rq_device_free(e, d_nm));
     }
     print_i32(commit_out, G);
     for (uint32_t p = 0; p < n; p++) print_i32(voter_term_out + (size_t)p * G, G);

@@ -24,10 +24,15 @@ def run_cli(mode, b):
         a = np.asarray(b[k])
         a = a[:, :G] if a.ndim == 2 else a
         parts.append(" ".join(str(int(x)) for x in a.ravel()))
+    if mode in ("segmented", "rounds"):
+        parts.append(" ".join(str(int(x)) for x in b["old_mask"][:G]))
+        parts.append(" ".join(str(int(x)) for x in b["new_mask"][:G]))
     p = subprocess.run([CLI, mode], input="\n".join(parts) + "\n", capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stderr
     rows = [np.array(line.split(), dtype=np.int64) for line in p.stdout.strip().split("\n")]
     assert len(rows) == n + 6
+    if mode == "segmented":
+        run_cli.segments = int(p.stderr.split("rq_cli:")[-1].split()[0])
     return dict(commit=rows[0], voter_term=np.stack(rows[1:1 + n]), grant_mask=rows[1 + n],
                 stepdown_mask=rows[2 + n], elected=rows[3 + n], max_term=rows[4 + n], status=rows[5 + n])
 
@@ -70,6 +75,23 @@ def test_cli_known_answers_and_seeded_batch(mode):
     exp = o.fused_round(*b.fused_args())
     for f in ("commit", "voter_term", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
         assert np.array_equal(r[f], exp[f].astype(np.int64)), f
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["segmented", "rounds"])
+def test_cli_groups_of_different_sizes_from_plain_c(mode):
+    """Mixed 3-9 clusters + joint consensus in size order from a C program: `segmented` fills the
+    size table of rq_round_desc itself, `rounds` cuts the state into two images for one
+    rq_plan_rounds launch -- both against the oracle's member-mask round."""
+    b = synth.gen_mixed(2500, seed=77, bucketed="size")
+    r = run_cli(mode, b)
+    exp = o.fused_round(*b.fused_args(), G=b.G, old_mask=b.old_mask, new_mask=b.new_mask)
+    for f in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
+        assert np.array_equal(r[f], exp[f].astype(np.int64)), f
+    mem = (((b.old_mask | b.new_mask).astype(np.int64)[None, :] >> np.arange(b.n)[:, None]) & 1).astype(bool)
+    assert np.array_equal(r["voter_term"][mem], exp["voter_term"][:, :b.G].astype(np.int64)[mem])
+    if mode == "segmented":
+        assert 8 <= run_cli.segments <= 16
 
 
 @pytest.mark.gpu
