@@ -247,6 +247,30 @@ def segment_table(old_mask, new_mask, max_segments=16):
     return first_group, [int(kind[t]) for t in starts]
 
 
+def reorder(b, order):
+    """The batch with its groups in the order `order` (a permutation of range(G)): every
+    per-group and per-slot array permuted, the log arena rebuilt in the new order."""
+    G = int(b["G"])
+    order = np.asarray(order, dtype=np.int64)
+    out = Batch(b)
+    out["ld"] = G
+    for k, a in b.items():
+        if not isinstance(a, np.ndarray) or k in ("log_off", "log_term"):
+            continue
+        if a.ndim == 2:
+            out[k] = np.ascontiguousarray(a[:, :G][:, order])
+        elif a.ndim == 1 and a.size >= G:
+            out[k] = np.ascontiguousarray(a[:G][order])
+    off = b["log_off"].astype(np.int64)
+    lens = np.diff(off)[order]
+    new_off = _csr(lens)
+    total = int(new_off[-1])
+    src = np.repeat(off[:-1][order] - new_off[:-1].astype(np.int64), lens) + np.arange(total, dtype=np.int64)
+    out["log_off"] = new_off
+    out["log_term"] = b["log_term"][src] if total else b["log_term"][:0]
+    return out
+
+
 def split_by_size(b, max_images=16):
     """A mixed batch ordered by cluster size (gen_mixed(bucketed="size")) as separate
     images, one per run of equal kind: [(kind, lo, hi, sub-batch)].  kind n = 1..9: the

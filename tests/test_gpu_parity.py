@@ -1080,6 +1080,71 @@ def test_fuzz_layouts_windows_and_summaries(dev):
             assert res["summary_escapes"] == int((~fit).sum()), case
 
 
+def test_fuzz_size_tables_and_images(dev):
+    """Random populations of 1..9-peer clusters and groups in joint consensus, laid out in random
+    runs of equal size (sorted, reversed, shuffled runs, runs that end inside a tile), launched with
+    the size table synth.segment_table derives -- or, when the order needs more than 16 segments,
+    without one -- and as separate images in one rq_plan_rounds launch; random layout, width,
+    arena form and decision set.  Everything against the oracle's member-mask round."""
+    from raft_amd.device import DeviceBatch
+    rng = np.random.default_rng(_fuzz_seed(3131))
+    tables = images = 0
+    for it in range(_fuzz_iters(48)):
+        G = int(rng.integers(1, 6000))
+        lo = int(rng.integers(1, 8)); hi = int(rng.integers(lo, 10))
+        b = synth.gen_mixed(G, seed=_fuzz_data(12000 + it), bucketed="size", joint_frac=float(rng.choice([0.0, 0.1, 0.5])),
+                            n_lo=lo, n_hi=hi)
+        kind = str(rng.choice(["sorted", "reversed", "runs", "ragged"]))
+        if kind == "reversed":
+            b = synth.reorder(b, np.arange(G)[::-1])
+        elif kind in ("runs", "ragged") and G > 200:
+            # cut the sorted order into pieces (at tile boundaries, or anywhere) and shuffle the pieces
+            cuts = np.sort(rng.choice(np.arange(1, G), size=int(rng.integers(1, 12)), replace=False))
+            if kind == "runs":
+                cuts = np.unique(cuts // 64 * 64)
+                cuts = cuts[cuts > 0]
+            pieces = np.split(np.arange(G), cuts)
+            b = synth.reorder(b, np.concatenate([pieces[i] for i in rng.permutation(len(pieces))]))
+        tiled, wide = bool(rng.integers(2)), bool(rng.integers(4) == 0)
+        what = int(rng.choice([3, 3, 1, 2]))
+        by_start = bool(rng.integers(4) == 0)
+        if by_start:
+            b = synth.raft_valid(b)
+        exp = o.fused_round(*b.fused_args(), G=G, old_mask=b.old_mask, new_mask=b.new_mask)
+        mem = member_matrix(b)
+        segs = synth.segment_table(b.old_mask, b.new_mask)
+        batch = synth.widen(b)[0] if wide else b
+        akw = dict(term_start=True) if by_start else dict(log_term_bits=[None, 0][int(rng.integers(2))])
+        case = (it, G, lo, hi, kind, tiled, wide, what, by_start, None if segs is None else segs[1])
+
+        def check(res, e, m, G_, full_status):
+            if what & 1:
+                assert np.array_equal(res["commit"].astype(np.int64), e["commit"][:G_].astype(np.int64)), case
+            if what & 2:
+                for f in ("grant_mask", "stepdown_mask", "elected", "max_term"):
+                    assert np.array_equal(res[f].astype(np.int64), e[f][:G_].astype(np.int64)), (f, case)
+                assert np.array_equal(res["voter_term"][:, :G_][m].astype(np.int64), e["voter_term"][:, :G_][m].astype(np.int64)), case
+            if full_status:
+                assert np.array_equal(res["status"], e["status"][:G_]), case
+
+        db = DeviceBatch(batch, tiled=tiled, segments=segs, **akw)
+        dev.round(db, what)
+        check(db.results(), exp, mem, G, what == 3)
+        tables += segs is not None
+        parts = synth.split_by_size(b)
+        if parts is not None and not by_start:
+            wparts = synth.split_by_size(batch)
+            imgs = []
+            for k, lo_, hi_, sub in wparts:
+                imgs.append(DeviceBatch(sub, tiled=tiled, share_log_with=imgs[0] if imgs else None, own_log_off=True))
+            dev.launch_plan(dev.plan_rounds(imgs, what))
+            for im, (k, lo_, hi_, sub) in zip(imgs, parts):
+                e = {f: (exp[f][:sub.n, lo_:hi_] if f == "voter_term" else exp[f][lo_:hi_]) for f in ("commit", "voter_term") + VOTE_FIELDS}
+                check(im.results(), e, member_matrix(sub) if k == 0 else np.ones((sub.n, sub.G), bool), hi_ - lo_, what == 3)
+            images += 1
+    assert tables >= _fuzz_iters(48) // 3 and images >= _fuzz_iters(48) // 4
+
+
 def test_two_streams_on_one_engine(dev):
     """Device-pointer launches keep no state in the engine: two torch streams drive
     the same engine handle at the same time on different batches."""
