@@ -133,7 +133,7 @@ def parse():
                          "prepared launch and touches every buffer)")
     ap.add_argument("--strong-total", type=int, default=8388608,
                     help="2 or 4 ranks: total groups of the additional strong-scaling figure (extra.strong_8m)")
-    ap.add_argument("--watchdog-seconds", type=float, default=60.0,
+    ap.add_argument("--watchdog-seconds", type=float, default=90.0,
                     help="a rank that retires no step for this long dumps its stacks and exits with code 3 (0 = off)")
     ap.add_argument("--launcher-timeout", type=float, default=540.0,
                     help="--gpus N without a launcher: give up, and kill every rank, after this many seconds")
@@ -661,6 +661,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        # the communicator is built by the first collective (seconds on a full node): here, where
+        # no watchdog is armed and nothing is timed
+        warm = torch.zeros(1, device=device)
+        dist.all_reduce(warm)
+        torch.cuda.synchronize(device)
 
     if args.summary == "auto":
         args.summary = "u8" if args.workload == "fused" else "u16"
