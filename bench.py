@@ -676,13 +676,13 @@ def main():
         step=state.get("step"), phase=state.get("phase"), exchange=state["ex"].debug_state() if state.get("ex") else None))
     hang_rank, hang_step = (int(x) for x in os.environ.get("RQ_BENCH_INJECT_HANG", "-1:-1").split(":"))
 
-    def measure(G, S, steps, warmup, preheat_rotations, label):
+    def measure(G, S, steps, warmup, preheat_rotations, label, rounds_per_exchange=None):
         """Build S rotating input/output sets of G groups on this rank, run the untimed rotations,
         then time `steps` steps with the exchange (if any) and -- with more than one rank or a forced
         exchange -- the same steps again without it, so that one invocation separates the kernels'
         scaling from the cost of the exchange."""
         n = args.peers
-        R = max(1, min(args.rounds_per_exchange, S))
+        R = max(1, min(rounds_per_exchange or args.rounds_per_exchange, S))
         while S % R:
             R -= 1                                   # every input set maps to one (slot, round-in-slot)
         depth = S // R
@@ -949,7 +949,8 @@ def main():
         ex = consumer = m["ex"] = m["consumer"] = None
         torch.cuda.empty_cache()
         total8 = args.strong_total
-        m8 = measure(total8 // world, 4, args.steps, args.warmup, 2, "strong_8m")
+        # 4 sets as 2 exchange slots of 2 rounds, so that a slot's all-gather overlaps the other slot's rounds
+        m8 = measure(total8 // world, 4, args.steps, args.warmup, 2, "strong_8m", rounds_per_exchange=2)
         w8 = over_ranks(m8["wall"], dist.ReduceOp.MAX)
         v8 = verify_against_oracle(m8["sets"][0], m8["verify_host"], what=3)
         ok8 = over_ranks(1.0 if v8["ok"] else 0.0, dist.ReduceOp.MIN) == 1.0
