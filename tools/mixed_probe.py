@@ -1,6 +1,6 @@
 """GPU: the mixed / joint workload (1M groups of 3-9 peers, 10 % in joint consensus, Zipf logs)
 decided three ways -- every group through its member masks with the groups ordered by highest
-slot (the layout of earlier rounds), the same with the groups ordered by cluster size, and the
+slot, the same with the groups ordered by cluster size, and the
 size order launched with the segment table -- each with the log-term lookup and without
 (log_term_start).  Prints one JSON object; set 0 of every variant is checked against the oracle.
 
