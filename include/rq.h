@@ -470,6 +470,7 @@ int rq_plan_rounds(rq_engine *e, const rq_round_desc *descs, uint32_t count, rq_
  * pointers, raft.go:26). */
 int rq_stream_wait_signal(rq_engine *e, void *stream, const uint64_t *signal, uint64_t value);
 int rq_plan_launch(rq_plan *p, void *stream);
+/* A plan made by rq_plan_rounds owns device memory: destroying it waits for the device. */
 int rq_plan_destroy(rq_plan *p);
 
 /* AppendEntries consistency batch on device buffers: the fields of

@@ -417,6 +417,19 @@ class DeviceBatch:
         )
 
 
+class RoundsPlan:
+    """An rq_plan over several images (DeviceEngine.plan_rounds): owns the plan handle and keeps
+    the images it names alive for as long as it can be launched."""
+
+    def __init__(self, l, handle, batches):
+        self._l, self.handle, self.batches = l, handle, batches
+
+    def __del__(self):
+        if getattr(self, "handle", None):
+            self._l.rq_plan_destroy(self.handle)
+            self.handle = None
+
+
 class DeviceEngine:
     """rq_engine handle used only for its device binding; buffers are the caller's."""
 
@@ -533,8 +546,8 @@ class DeviceEngine:
 
     def plan_rounds(self, batches, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
         """ONE prepared launch over several DeviceBatch images (rq_plan_rounds): each keeps its
-        own arrays, cluster size or member masks and tiling.  Returns a handle for launch_plan();
-        the plan is destroyed with the first batch."""
+        own arrays, cluster size or member masks and tiling.  Returns a RoundsPlan for
+        launch_plan(); it keeps the batches (and so their device buffers) alive."""
         descs = (RoundDesc * len(batches))()
         for i, b in enumerate(batches):
             descs[i] = self.describe(b, what, variant, want_bits, status)
@@ -542,11 +555,10 @@ class DeviceEngine:
         rc = self._l.rq_plan_rounds(self._h, descs, len(batches), C.byref(plan))
         if rc != 0:
             self._check(rc, "rq_plan_rounds")
-        batches[0]._plans.append((self._l, plan))
-        return plan
+        return RoundsPlan(self._l, plan, list(batches))
 
     def launch_plan(self, plan):
-        rc = self._l.rq_plan_launch(plan, torch.cuda.current_stream().cuda_stream)
+        rc = self._l.rq_plan_launch(plan.handle, torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             self._check(rc, "rq_plan_launch")
 

@@ -450,7 +450,8 @@ def test_full_size_1m_mixed_sizes_and_joint_consensus(dev):
     _check_dev(db.results(), exps, G, member_matrix(bs))
     arena = db
     imgs = [DeviceBatch(sub, tiled=True, share_log_with=arena, own_log_off=True) for _, _, _, sub in synth.split_by_size(bs)]
-    dev.launch_plan(dev.plan_rounds(imgs))
+    plan = dev.plan_rounds(imgs)
+    dev.launch_plan(plan)
     for im, (k, lo, hi, sub) in zip(imgs, synth.split_by_size(bs)):
         r = im.results()
         part = {f: (exps[f][:sub.n, lo:hi] if f == "voter_term" else exps[f][lo:hi]) for f in ("commit", "voter_term") + VOTE_FIELDS}
@@ -1137,7 +1138,8 @@ def test_fuzz_size_tables_and_images(dev):
             imgs = []
             for k, lo_, hi_, sub in wparts:
                 imgs.append(DeviceBatch(sub, tiled=tiled, share_log_with=imgs[0] if imgs else None, own_log_off=True))
-            dev.launch_plan(dev.plan_rounds(imgs, what))
+            plan = dev.plan_rounds(imgs, what)
+            dev.launch_plan(plan)
             for im, (k, lo_, hi_, sub) in zip(imgs, parts):
                 e = {f: (exp[f][:sub.n, lo_:hi_] if f == "voter_term" else exp[f][lo_:hi_]) for f in ("commit", "voter_term") + VOTE_FIELDS}
                 check(im.results(), e, member_matrix(sub) if k == 0 else np.ones((sub.n, sub.G), bool), hi_ - lo_, what == 3)
