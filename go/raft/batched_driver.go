@@ -282,6 +282,10 @@ func apply[T word](d *BatchedDriver, b *roundBuffers[T]) {
 			if leaderBefore != nil {
 				leaderBefore.commitIndex = int(b.commitOut[g])
 			}
+			// a leader a vote request demoted (raft.go:221) leads no more
+			if grp.Leader != nil && grp.Leader.nodeType != Leader {
+				grp.Leader = nil
+			}
 		}
 	})
 }
@@ -294,8 +298,10 @@ func apply[T word](d *BatchedDriver, b *roundBuffers[T]) {
 // RequestVoteRPC); the round is applied either way.
 //
 // Step flattens every Node and moves the whole image over PCIe both ways: fine
-// for thousands of groups, tens of milliseconds for a million. ResidentDriver
-// keeps the image in HBM and moves only the groups the host touched.
+// for thousands of groups, tens of milliseconds for a million. A resident
+// driver keeps the image in HBM and moves only the groups the host touched: its
+// cgo calls are in resident_driver.go, its logic in the C++ host
+// (raft_amd/csrc/host/raft_host_resident.cpp).
 func (d *BatchedDriver) Step() error {
 	err := flatten(d, compact, &d.buf32)
 	if err == errRange {
