@@ -560,6 +560,18 @@ def test_segment_table_is_checked_and_a_wrong_one_is_not_a_fault(dev):
         for i, v in enumerate(kinds[:16]):
             d.seg_n[i] = v
         assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == -1, (first, kinds)
+    # an empty batch with a table, and an empty segment inside a table, are fine
+    d = dev.describe(db)
+    d.G, d.n_segments = 0, 1
+    d.seg_first_group[0] = d.seg_first_group[1] = 0
+    d.seg_n[0] = 3
+    assert dev._l.rq_round_dev(dev._h, None, C.byref(d)) == 0
+    segs = synth.segment_table(b.old_mask, b.new_mask)
+    first, kinds = list(segs[0]), list(segs[1])
+    first.insert(2, first[1]); kinds.insert(1, 7)            # [a, b) -> [a, b), [b, b): an empty run of 7-peer clusters
+    db2 = DeviceBatch(b, tiled=True, segments=(first, kinds))
+    dev.fused_round(db2)
+    _check_dev(db2.results(), o.fused_round(*b.fused_args(), G=G, old_mask=b.old_mask, new_mask=b.new_mask), G, member_matrix(b))
     lie = ([0, 6400, G], [4, 0])                 # the first 6400 groups are not all clusters of 4
     db = DeviceBatch(b, tiled=True, segments=lie)
     dev.fused_round(db)
@@ -613,6 +625,18 @@ def test_rounds_in_one_launch(dev):
     dev.launch_plan(plan)
     for db, hb in zip(imgs, bs):
         _check_dev(db.results(), o.fused_round(*hb.fused_args(), G=hb.G), hb.G)
+    # an image without groups among the others changes nothing; a launch of empty images only is a no-op
+    descs = (RoundDesc * 3)()
+    descs[0], descs[1], descs[2] = dev.describe(imgs[1]), dev.describe(imgs[0]), dev.describe(imgs[3])
+    descs[1].G = 0
+    out = C.c_void_p()
+    assert dev._l.rq_plan_rounds(dev._h, descs, 3, C.byref(out)) == 0
+    assert dev._l.rq_plan_launch(out, None) == 0
+    for db, hb in ((imgs[1], bs[1]), (imgs[3], bs[3])):
+        _check_dev(db.results(), o.fused_round(*hb.fused_args(), G=hb.G), hb.G)
+    assert dev._l.rq_plan_destroy(out) == 0
+    assert dev._l.rq_plan_rounds(dev._h, C.byref(descs[1]), 1, C.byref(out)) == 0
+    assert dev._l.rq_plan_launch(out, None) == 0 and dev._l.rq_plan_destroy(out) == 0
     # refusals: no images, too many, mixed layouts / decision sets, a segment table inside
     descs = (RoundDesc * 17)()
     for i in range(17):
