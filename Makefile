@@ -3,9 +3,12 @@
 HIPCC   ?= hipcc
 CC      ?= gcc
 ARCH    ?= gfx950
+# -amdgpu-kernarg-preload-count: the leading scalar arguments of a kernel (up to 14 dwords on
+# gfx950) arrive in SGPRs with the wave instead of being fetched by its first scalar loads;
+# rq_round_fixed orders its arguments for it (rq_round_impl.h).
 # PLAIN=1 also builds the round kernels with the default cache policy (RQ_VARIANT_PLAIN;
 # a library without them runs the streaming builds for that variant, results are the same)
-HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function $(if $(PLAIN),-DRQ_BUILD_PLAIN)
+HIPFLAGS = -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Wall -Wno-unused-function $(if $(PLAIN),-DRQ_BUILD_PLAIN) -mllvm -amdgpu-kernarg-preload-count=16
 CSRC     = raft_amd/csrc
 
 all: raft_amd/librq.so raft_amd/libraft_host.so oracle/librq_oracle.so examples/rq_cli examples/rq_bench

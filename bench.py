@@ -27,6 +27,7 @@ touches torch or the GPU -- and relays rank 0's line.
 Rank 0 prints ONE JSON line.
 """
 import argparse
+import gc
 import hashlib
 import json
 import os
@@ -363,20 +364,39 @@ def verify_against_oracle(db, hb, what=3, want_bits=True, status=True):
 def timed_launches(torch, device, launch, steps, warmup, preheat):
     """HIP-event time per launch of launch(i) on the current stream: `preheat`
     untimed launches (first touch, prepared launches built), `warmup` more, then
-    `steps` timed ones."""
+    `steps` timed ones.  The timed launches are bracketed in four runs of steps / 4 by
+    events recorded between them and the median run is reported, and Python's cyclic
+    garbage collector is held off while launches are being enqueued: a full collection in
+    a process that has imported torch takes tens of milliseconds, the queue runs dry
+    meanwhile, and whichever figure that landed in read ten times too slow."""
     for i in range(preheat):
         launch(i)
     torch.cuda.synchronize(device)
     for i in range(warmup):
         launch(i)
     torch.cuda.synchronize(device)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for i in range(steps):
-        launch(i)
-    e1.record()
-    torch.cuda.synchronize(device)
-    return e0.elapsed_time(e1) / steps
+    runs = 4 if steps >= 40 else 1
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(runs + 1)]
+    bounds = [steps * r // runs for r in range(runs + 1)]
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        marks[0].record()
+        for r in range(runs):
+            for i in range(bounds[r], bounds[r + 1]):
+                launch(i)
+            marks[r + 1].record()
+        torch.cuda.synchronize(device)
+    finally:
+        if gc_was_on:
+            gc.enable()
+    raw = [marks[r].elapsed_time(marks[r + 1]) / (bounds[r + 1] - bounds[r]) for r in range(runs)]
+    per = sorted(raw)
+    mid = per[(runs - 1) // 2]
+    if per[-1] > 2 * mid:
+        sys.stderr.write("bench.py: one run of a timed region stalled: ms per launch by run %s, median taken\n"
+                         % [round(x, 4) for x in raw])
+    return mid
 
 
 def extras(args, torch, synth, DeviceBatch, eng, device, host_batches, out):
@@ -792,16 +812,22 @@ def main():
                 step(i, with_ex)
             fence(with_ex)
             state["phase"] = label + ":timed"
-            t0 = time.perf_counter()
-            ev0.record()
-            for i in range(steps):
-                step(i, with_ex)
-            ev1.record()                              # same stream as the kernels
-            t_enqueued = time.perf_counter()
-            if ex is not None and with_ex:
-                ex.wait_all()
-            eng.stream_sync()                         # polls the kernels' stream: a blocked thread wakes 10-20 us late
-            t1 = time.perf_counter()
+            gc_was_on = gc.isenabled()
+            gc.disable()              # a full collection (tens of ms with torch imported) would let the queue run dry
+            try:
+                t0 = time.perf_counter()
+                ev0.record()
+                for i in range(steps):
+                    step(i, with_ex)
+                ev1.record()                              # same stream as the kernels
+                t_enqueued = time.perf_counter()
+                if ex is not None and with_ex:
+                    ex.wait_all()
+                eng.stream_sync()                         # polls the kernels' stream: a blocked thread wakes 10-20 us late
+                t1 = time.perf_counter()
+            finally:
+                if gc_was_on:
+                    gc.enable()
             fence(with_ex)
             return t1 - t0, ev0.elapsed_time(ev1) / steps, t_enqueued - t0
 

@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librq.so")
+# RQ_LIBRARY: another build of the same library (A/B measurements); the default is the in-tree one
+LIB_PATH = os.environ.get("RQ_LIBRARY") or os.path.join(_HERE, "librq.so")
 
 i32p = C.POINTER(C.c_int32)
 u32p = C.POINTER(C.c_uint32)

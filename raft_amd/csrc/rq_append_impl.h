@@ -52,16 +52,16 @@ __device__ __forceinline__ commit_inputs<T> load_commit_inputs(const rq_round_ar
     commit_inputs<T> in;
     const group_addr ga = addr_of(r, g);
     in.lt = 0; in.lb = 0; in.tb = 0; in.ts = 0; in.beg = 0; in.end = 0; in.ln = 0;
-    in.cm = __builtin_nontemporal_load(at(r.commit, ga));
-    if (r.log_base) in.lb = __builtin_nontemporal_load(at(r.log_base, ga));
-    if (r.log_len) in.ln = __builtin_nontemporal_load(at(r.log_len, ga));
+    in.cm = __builtin_nontemporal_load(gptr(at(r.commit, ga)));
+    if (r.log_base) in.lb = __builtin_nontemporal_load(gptr(at(r.log_base, ga)));
+    if (r.log_len) in.ln = __builtin_nontemporal_load(gptr(at(r.log_len, ga)));
     if (r.log_term_start) {
-        in.ts = __builtin_nontemporal_load(at(r.log_term_start, ga));
+        in.ts = __builtin_nontemporal_load(gptr(at(r.log_term_start, ga)));
     } else {
-        in.lt = __builtin_nontemporal_load(at(r.leader_term, ga));
-        if (r.log_term_base) in.tb = __builtin_nontemporal_load(at(r.log_term_base, ga));
-        in.beg = __builtin_nontemporal_load(at(r.log_off, ga));
-        in.end = *at(r.log_off, addr_of(r, g + 1));
+        in.lt = __builtin_nontemporal_load(gptr(at(r.leader_term, ga)));
+        if (r.log_term_base) in.tb = __builtin_nontemporal_load(gptr(at(r.log_term_base, ga)));
+        in.beg = __builtin_nontemporal_load(gptr(at(r.log_off, ga)));
+        in.end = *gptr(at(r.log_off, addr_of(r, g + 1)));
     }
     return in;
 }
@@ -110,13 +110,13 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     const size_t ld = a.ld;
     const uint32_t n = a.n;
     const size_t gT = append_index<TILED, T>(a.tile_bytes, ld, g, 0);
-    const T lt = __builtin_nontemporal_load(a.leader_term + gT);
-    const T tbase = a.flog_term_base ? __builtin_nontemporal_load(a.flog_term_base + gT) : (T)0;
-    uint32_t act = a.active_mask ? (uint32_t)a.active_mask[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)] : 0xFFFFu;
+    const T lt = __builtin_nontemporal_load(gptr(a.leader_term + gT));
+    const T tbase = a.flog_term_base ? __builtin_nontemporal_load(gptr(a.flog_term_base + gT)) : (T)0;
+    uint32_t act = a.active_mask ? (uint32_t)gptr(a.active_mask)[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)] : 0xFFFFu;
     act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
     const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
     constexpr bool clamp = CLAMP;
-    const T lc = clamp ? __builtin_nontemporal_load(a.leader_commit + gT) : (T)0;
+    const T lc = clamp ? __builtin_nontemporal_load(gptr(a.leader_commit + gT)) : (T)0;
     T ft[NMAX], pi[NMAX], pt[NMAX], nn[NMAX], mi[NMAX], ni[NMAX], tg[NMAX], fb[NMAX], fc[NMAX], li[NMAX];
     uint32_t o0[NMAX], o1[NMAX];
 #pragma unroll
@@ -125,23 +125,23 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
         if ((act >> p) & 1u) {
             const size_t s = append_index<TILED, T>(a.tile_bytes, ld, g, p);
             const size_t so = append_index<TILED, uint32_t>(a.tile_bytes, ld, g, p);
-            ft[p] = __builtin_nontemporal_load(a.follower_term + s);
-            pi[p] = __builtin_nontemporal_load(a.prev_log_index + s);
-            pt[p] = __builtin_nontemporal_load(a.prev_log_term + s);
-            o0[p] = __builtin_nontemporal_load(a.flog_off + so);
+            ft[p] = __builtin_nontemporal_load(gptr(a.follower_term + s));
+            pi[p] = __builtin_nontemporal_load(gptr(a.prev_log_index + s));
+            pt[p] = __builtin_nontemporal_load(gptr(a.prev_log_term + s));
+            o0[p] = __builtin_nontemporal_load(gptr(a.flog_off + so));
             // the end of the log = the next entry: plain load, the neighbour's line is already on its way
-            o1[p] = TILED ? a.flog_off[append_index<TILED, uint32_t>(a.tile_bytes, ld, g + 1, p)] : a.flog_off[so + 1];
-            if (a.flog_base) fb[p] = __builtin_nontemporal_load(a.flog_base + s);
-            if (a.n_new) nn[p] = __builtin_nontemporal_load(a.n_new + s);
-            if (a.match_index_io) mi[p] = __builtin_nontemporal_load(a.match_index_io + s);
-            if (a.next_index_io) ni[p] = __builtin_nontemporal_load(a.next_index_io + s);
+            o1[p] = TILED ? gptr(a.flog_off)[append_index<TILED, uint32_t>(a.tile_bytes, ld, g + 1, p)] : gptr(a.flog_off)[so + 1];
+            if (a.flog_base) fb[p] = __builtin_nontemporal_load(gptr(a.flog_base + s));
+            if (a.n_new) nn[p] = __builtin_nontemporal_load(gptr(a.n_new + s));
+            if (a.match_index_io) mi[p] = __builtin_nontemporal_load(gptr(a.match_index_io + s));
+            if (a.next_index_io) ni[p] = __builtin_nontemporal_load(gptr(a.next_index_io + s));
             if constexpr (clamp) {
-                fc[p] = __builtin_nontemporal_load(a.follower_commit_io + s);
-                li[p] = __builtin_nontemporal_load(a.last_new_index + s);
+                fc[p] = __builtin_nontemporal_load(gptr(a.follower_commit_io + s));
+                li[p] = __builtin_nontemporal_load(gptr(a.last_new_index + s));
             }
         } else if constexpr (COMMIT) {
             // a slot without an RPC still counts in the commit round: its stored matchIndex
-            if ((uint32_t)p < r.m) mi[p] = __builtin_nontemporal_load(a.match_index_io + append_index<TILED, T>(a.tile_bytes, ld, g, p));
+            if ((uint32_t)p < r.m) mi[p] = __builtin_nontemporal_load(gptr(a.match_index_io + append_index<TILED, T>(a.tile_bytes, ld, g, p)));
         }
     }
     // COMMIT: matchIndex of every slot the commit round counts -- what this batch produces stays
@@ -181,13 +181,13 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
         sd |= (uint32_t)(lt > ft[p]) << p;
         ok |= (uint32_t)success << p;
         st |= (rch && !in) ? kStLogOob : 0;
-        __builtin_nontemporal_store(tmax(ft[p], lt), a.follower_term_out + append_index<TILED, T>(fo_tile, ld, g, p));
+        __builtin_nontemporal_store(tmax(ft[p], lt), gptr(a.follower_term_out + append_index<TILED, T>(fo_tile, ld, g, p)));
         if (upd) {
             T m2 = mi[p], n2 = ni[p];
             if (success) { m2 = (T)((U)pi[p] + (U)nn[p]); n2 = (T)((U)m2 + (U)1); }
             else if (rch) { n2 = n2 > 1 ? n2 - 1 : 1; }
-            if (a.match_index_io) __builtin_nontemporal_store(m2, a.match_index_io + s);
-            if (a.next_index_io) __builtin_nontemporal_store(n2, a.next_index_io + s);
+            if (a.match_index_io) __builtin_nontemporal_store(m2, gptr(a.match_index_io + s));
+            if (a.next_index_io) __builtin_nontemporal_store(n2, gptr(a.next_index_io + s));
             if constexpr (COMMIT) { if (a.match_index_io) mv[p] = m2; }
         }
         if constexpr (clamp) {
@@ -196,13 +196,13 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
                 if (a.n_new && nn[p] == 0) st |= kStEmptyLog;             // lastEntry of no entries, :175 / :235
                 else c2 = tmin(lc, li[p]);
             }
-            __builtin_nontemporal_store(c2, a.follower_commit_io + s);
+            __builtin_nontemporal_store(c2, gptr(a.follower_commit_io + s));
         }
     }
     const size_t g16 = append_index<TILED, uint16_t>(out_tile, ld, g, 0);
-    __builtin_nontemporal_store((uint16_t)ok, a.success_mask + g16);
-    __builtin_nontemporal_store((uint16_t)sd, a.stepdown_mask + g16);
-    if (a.status_out) a.status_out[append_index<TILED, uint8_t>(out_tile, ld, g, 0)] = (uint8_t)st;
+    __builtin_nontemporal_store((uint16_t)ok, gptr(a.success_mask + g16));
+    __builtin_nontemporal_store((uint16_t)sd, gptr(a.stepdown_mask + g16));
+    if (a.status_out) gptr(a.status_out)[append_index<TILED, uint8_t>(out_tile, ld, g, 0)] = (uint8_t)st;
     if constexpr (COMMIT) {
         // the round's own inputs are read here, after the batch's stores: issued with the batch's
         // planes they cost 40 registers and half the resident waves
@@ -211,13 +211,13 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
         if (r.tile_bytes) rgo.tile_off = (size_t)(g >> 6) * r.out_tile_bytes;
         const group_addr gco = (const void *)r.commit_out == (const void *)r.commit ? rga : rgo;
         if constexpr (L > NMAX) {
-            if (r.m > (uint32_t)NMAX) mv[NMAX] = __builtin_nontemporal_load(at(r.match, rga, NMAX));
+            if (r.m > (uint32_t)NMAX) mv[NMAX] = __builtin_nontemporal_load(gptr(at(r.match, rga, NMAX)));
         }
         const commit_inputs<T> cin = load_commit_inputs(r, g);
         uint32_t rst = 0;
         const T co = commit_decision(r, cin, live_quorum<L>(mv, r.m), rst);
-        __builtin_nontemporal_store(co, at(r.commit_out, gco));
-        if (r.status_out) *at(r.status_out, rgo) = (uint8_t)rst;
+        __builtin_nontemporal_store(co, gptr(at(r.commit_out, gco)));
+        if (r.status_out) *gptr(at(r.status_out, rgo)) = (uint8_t)rst;
     }
 }
 

@@ -35,8 +35,14 @@ template <typename T> constexpr T kMinOf = std::numeric_limits<T>::min();
 // vector load/store helpers
 // ---------------------------------------------------------------------------
 // r[0..V) = p[0..V) (FULL: one aligned vector load; else first `valid` only).
+// Every array these helpers touch is device (global) memory: saying so lets the compiler emit
+// global_load / global_store instead of flat accesses.
+#define RQ_GLOBAL __attribute__((address_space(1)))
+template <typename P>
+__device__ __forceinline__ RQ_GLOBAL P *gptr(P *p) { return (RQ_GLOBAL P *)p; }
 template <int V, bool NT, bool FULL, typename T>
-__device__ __forceinline__ void ld_i32(const T *p, int valid, T (&r)[V]) {
+__device__ __forceinline__ void ld_i32(const T *pg, int valid, T (&r)[V]) {
+    const RQ_GLOBAL T *p = (const RQ_GLOBAL T *)pg;
     if constexpr (!FULL) {
 #pragma unroll
         for (int k = 0; k < V; k++) r[k] = k < valid ? p[k] : 0;
@@ -44,7 +50,7 @@ __device__ __forceinline__ void ld_i32(const T *p, int valid, T (&r)[V]) {
         r[0] = NT ? __builtin_nontemporal_load(p) : *p;
     } else {
         typedef T vt __attribute__((ext_vector_type(V)));
-        const vt *vp = reinterpret_cast<const vt *>(p);
+        const RQ_GLOBAL vt *vp = (const RQ_GLOBAL vt *)p;
         vt v = NT ? __builtin_nontemporal_load(vp) : *vp;
 #pragma unroll
         for (int k = 0; k < V; k++) r[k] = v[k];
@@ -52,7 +58,8 @@ __device__ __forceinline__ void ld_i32(const T *p, int valid, T (&r)[V]) {
 }
 
 template <int V, bool NT, bool FULL, typename T>
-__device__ __forceinline__ void st_i32(T *p, int valid, const T (&r)[V]) {
+__device__ __forceinline__ void st_i32(T *pg, int valid, const T (&r)[V]) {
+    RQ_GLOBAL T *p = (RQ_GLOBAL T *)pg;
     if constexpr (!FULL) {
 #pragma unroll
         for (int k = 0; k < V; k++) if (k < valid) p[k] = r[k];
@@ -63,14 +70,15 @@ __device__ __forceinline__ void st_i32(T *p, int valid, const T (&r)[V]) {
         vt v;
 #pragma unroll
         for (int k = 0; k < V; k++) v[k] = r[k];
-        vt *vp = reinterpret_cast<vt *>(p);
+        RQ_GLOBAL vt *vp = (RQ_GLOBAL vt *)p;
         if (NT) __builtin_nontemporal_store(v, vp); else *vp = v;
     }
 }
 
 // V 16-bit values (low halves of r[k]) -> one 2*V-byte store.
 template <int V, bool NT, bool FULL>
-__device__ __forceinline__ void st_u16(uint16_t *p, int valid, const uint32_t (&r)[V]) {
+__device__ __forceinline__ void st_u16(uint16_t *pg, int valid, const uint32_t (&r)[V]) {
+    RQ_GLOBAL uint16_t *p = (RQ_GLOBAL uint16_t *)pg;
     if constexpr (!FULL) {
 #pragma unroll
         for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint16_t)r[k];
@@ -78,21 +86,22 @@ __device__ __forceinline__ void st_u16(uint16_t *p, int valid, const uint32_t (&
         if (NT) __builtin_nontemporal_store((uint16_t)r[0], p); else *p = (uint16_t)r[0];
     } else if constexpr (V == 2) {
         uint32_t w = (r[0] & 0xFFFFu) | (r[1] << 16);
-        uint32_t *wp = reinterpret_cast<uint32_t *>(p);
+        RQ_GLOBAL uint32_t *wp = (RQ_GLOBAL uint32_t *)p;
         if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
     } else {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
         u32x2 w;
         w[0] = (r[0] & 0xFFFFu) | (r[1] << 16);
         w[1] = (r[2] & 0xFFFFu) | (r[3] << 16);
-        u32x2 *wp = reinterpret_cast<u32x2 *>(p);
+        RQ_GLOBAL u32x2 *wp = (RQ_GLOBAL u32x2 *)p;
         if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
     }
 }
 
 // V 8-bit values -> one V-byte store.
 template <int V, bool NT, bool FULL>
-__device__ __forceinline__ void st_u8(uint8_t *p, int valid, const uint32_t (&r)[V]) {
+__device__ __forceinline__ void st_u8(uint8_t *pg, int valid, const uint32_t (&r)[V]) {
+    RQ_GLOBAL uint8_t *p = (RQ_GLOBAL uint8_t *)pg;
     if constexpr (!FULL) {
 #pragma unroll
         for (int k = 0; k < V; k++) if (k < valid) p[k] = (uint8_t)r[k];
@@ -100,28 +109,29 @@ __device__ __forceinline__ void st_u8(uint8_t *p, int valid, const uint32_t (&r)
         if (NT) __builtin_nontemporal_store((uint8_t)r[0], p); else *p = (uint8_t)r[0];
     } else if constexpr (V == 2) {
         const uint16_t w = (uint16_t)((r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8));
-        uint16_t *wp = reinterpret_cast<uint16_t *>(p);
+        RQ_GLOBAL uint16_t *wp = (RQ_GLOBAL uint16_t *)p;
         if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
     } else {
         uint32_t w = (r[0] & 0xFFu) | ((r[1] & 0xFFu) << 8) | ((r[2] & 0xFFu) << 16) | (r[3] << 24);
-        uint32_t *wp = reinterpret_cast<uint32_t *>(p);
+        RQ_GLOBAL uint32_t *wp = (RQ_GLOBAL uint32_t *)p;
         if (NT) __builtin_nontemporal_store(w, wp); else *wp = w;
     }
 }
 
 template <int V, bool FULL>
-__device__ __forceinline__ void ld_u16(const uint16_t *p, int valid, uint32_t (&r)[V]) {
+__device__ __forceinline__ void ld_u16(const uint16_t *pg, int valid, uint32_t (&r)[V]) {
+    const RQ_GLOBAL uint16_t *p = (const RQ_GLOBAL uint16_t *)pg;
     if constexpr (!FULL) {
 #pragma unroll
         for (int k = 0; k < V; k++) r[k] = k < valid ? p[k] : 0;
     } else if constexpr (V == 1) {
         r[0] = *p;
     } else if constexpr (V == 2) {
-        uint32_t w = *reinterpret_cast<const uint32_t *>(p);
+        uint32_t w = *(const RQ_GLOBAL uint32_t *)p;
         r[0] = w & 0xFFFFu; r[1] = w >> 16;
     } else {
         typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        u32x2 w = *reinterpret_cast<const u32x2 *>(p);
+        u32x2 w = *(const RQ_GLOBAL u32x2 *)p;
         r[0] = w[0] & 0xFFFFu; r[1] = w[0] >> 16;
         r[2] = w[1] & 0xFFFFu; r[3] = w[1] >> 16;
     }
@@ -225,13 +235,13 @@ __device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32
                                              uint64_t *bits) {
     if constexpr (V == 1) {
         unsigned long long w = __ballot(field & 1u);
-        if ((threadIdx.x & 63) == 0 && g0 < G) bits[g0 >> 6] = w;
+        if ((threadIdx.x & 63) == 0 && g0 < G) ((RQ_GLOBAL uint64_t *)bits)[g0 >> 6] = w;
     } else {
         constexpr int lanes_per_word = 64 / V;
         unsigned long long w = (unsigned long long)field << (g0 & 63);
 #pragma unroll
         for (int o = lanes_per_word / 2; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
-        if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) bits[g0 >> 6] = w;
+        if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) ((RQ_GLOBAL uint64_t *)bits)[g0 >> 6] = w;
     }
 }
 
@@ -242,7 +252,8 @@ constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02, kStBadCsr = 0x04;
 // -- a wave-uniform choice, so the switch is a scalar branch around loads of
 // different widths.  Its cache policy (a.nt_gather) is wave-uniform as well.
 template <typename P>
-__device__ __forceinline__ P load_one(const P *p, bool nt) {
+__device__ __forceinline__ P load_one(const P *pg, bool nt) {
+    const RQ_GLOBAL P *p = (const RQ_GLOBAL P *)pg;
     // two instructions behind a scalar branch: the hint is part of the encoding
     if (nt) return __builtin_nontemporal_load(p);
     return *p;
@@ -291,7 +302,7 @@ __device__ __forceinline__ uint32_t store_commit_summary(const rq_round_args_t<T
     for (int k = 0; k < V; k++) {
         T base = 0;
         if (base_is_input) base = cm[k];
-        else if (a.summary_base && k < valid) base = a.summary_base[g0 + k];
+        else if (a.summary_base && k < valid) base = ((const RQ_GLOBAL T *)a.summary_base)[g0 + k];
         // unsigned difference: exact whenever co >= base, whatever the magnitudes
         const uint64_t d = (uint64_t)(int64_t)co[k] - (uint64_t)(int64_t)base;
         const bool fit = co[k] >= base && d < escape;
@@ -331,7 +342,7 @@ __device__ __forceinline__ void pack_nibbles(uint32_t field, uint64_t g0, uint32
     unsigned long long w = (unsigned long long)field << (4 * (g0 & 15));
 #pragma unroll
     for (int o = lanes_per_word / 2; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
-    if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) words[g0 >> 4] = w;
+    if ((threadIdx.x & (lanes_per_word - 1)) == 0 && g0 < G) ((RQ_GLOBAL uint64_t *)words)[g0 >> 4] = w;
 }
 
 // What a round body hands back to the kernel for the wave-level packing.
@@ -408,11 +419,6 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     constexpr bool DO_COMMIT = (WHAT & RQ_WHAT_COMMIT) != 0;
     constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
     const group_addr ga = addr_of(a, g0);
-    group_addr go = ga;                       // outputs: their own tile block ...
-    if (a.tile_bytes) go.tile_off = (size_t)(g0 >> 6) * a.out_tile_bytes;
-    // ... unless they are the inputs themselves (state updated in place)
-    const group_addr gco = (const void *)a.commit_out == (const void *)a.commit ? ga : go;
-    const group_addr gvo = (const void *)a.voter_term_out == (const void *)a.voter_term ? ga : go;
 
     T mt[N][V], cm[V], lt[V], lb[V], tb[V], ts[V];
     int32_t off[V + 1], ln[V];
@@ -423,11 +429,26 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 #pragma unroll
     for (int k = 0; k < V; k++) st[k] = 0;
 
-    // ---- issue every streamed load up front ----
+    // ---- issue every streamed load up front: first the arrays whose pointers arrive with the
+    // wave (the kernel's leading arguments), then the ones named by the rest of the arguments ----
+    if constexpr (DO_VOTE) {
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            ld_i32<V, NTL, FULL>(at(a.voter_term, ga, p), valid, vt[p]);
+            ld_i32<V, NTL, FULL>(at(a.voted_for, ga, p), valid, vf[p]);
+            ld_i32<V, NTL, FULL>(at(a.last_log_term, ga, p), valid, ll[p]);
+        }
+    }
     if constexpr (DO_COMMIT) {
 #pragma unroll
         for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
         ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
+    }
+    if constexpr (DO_VOTE) {
+        ld_i32<V, NTL, FULL>(at(a.cand_term, ga), valid, ct);
+        ld_i32<V, NTL, FULL>(at(a.cand_id, ga), valid, ci);
+    }
+    if constexpr (DO_COMMIT) {
         if (a.log_term_start) {
             if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
             ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
@@ -444,22 +465,18 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
             ld_i32<V, NTL, FULL>(offp, valid, o);
             // plain on purpose: it re-reads the line the vector load above brought in
             // (non-temporal here bypasses L1 and was measured 1 us slower per round)
-            const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));  // log_off has G+1 entries
+            const int32_t oend = *(const RQ_GLOBAL int32_t *)at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));  // log_off has G+1 entries
 #pragma unroll
             for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
             off[V] = oend;
         }
     }
-    if constexpr (DO_VOTE) {
-#pragma unroll
-        for (int p = 0; p < N; p++) {
-            ld_i32<V, NTL, FULL>(at(a.voter_term, ga, p), valid, vt[p]);
-            ld_i32<V, NTL, FULL>(at(a.voted_for, ga, p), valid, vf[p]);
-            ld_i32<V, NTL, FULL>(at(a.last_log_term, ga, p), valid, ll[p]);
-        }
-        ld_i32<V, NTL, FULL>(at(a.cand_term, ga), valid, ct);
-        ld_i32<V, NTL, FULL>(at(a.cand_id, ga), valid, ci);
-    }
+
+    group_addr go = ga;                       // outputs: their own tile block ...
+    if (a.tile_bytes) go.tile_off = (size_t)(g0 >> 6) * a.out_tile_bytes;
+    // ... unless they are the inputs themselves (state updated in place)
+    const group_addr gco = (const void *)a.commit_out == (const void *)a.commit ? ga : go;
+    const group_addr gvo = (const void *)a.voter_term_out == (const void *)a.voter_term ? ga : go;
 
     // ---- commit: quorum index, then the dependent log-term gather ----
     T nq[V], gt[V];
@@ -538,15 +555,31 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     return round_fields{el_field, nib_field, esc_field, ch_field};
 }
 
+// The arguments a wave needs before it can issue its first loads -- the group count, the block
+// size, the layout's stride and the five arrays that make up most of the traffic -- travel as
+// leading scalar kernel arguments, 14 dwords: the build preloads those into SGPRs at wave launch
+// (kernarg preload), so the streamed loads go out at once while the rest of the argument
+// structure is still on its way from memory.  stride: bit 63 set = 64-group tiles of
+// (stride & ~bit 63) bytes, else the plane stride ld in elements.
+constexpr uint64_t kStrideTiled = 1ull << 63;
 template <int N, int V, int WHAT, bool NT, typename T>
-__global__ __launch_bounds__(kBlock) void rq_round_fixed(rq_round_args_t<T> a) {
-    signal_started(a);
-    const uint64_t g0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * V;
+__global__ __launch_bounds__(kBlock) void rq_round_fixed(uint32_t G, uint32_t block, uint64_t stride,
+                                                         const T *voter_term, const T *voted_for,
+                                                         const T *last_log_term, const T *match, const T *commit,
+                                                         rq_round_args_t<T> rest) {
+    rq_round_args_t<T> a = rest;
+    a.G = G;
+    a.tile_bytes = (stride & kStrideTiled) ? (stride & ~kStrideTiled) : 0;
+    a.ld = (stride & kStrideTiled) ? 0u : (uint32_t)stride;
+    a.match = match; a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = last_log_term;
+    a.commit = commit;
+    const uint64_t g0 = ((uint64_t)blockIdx.x * block + threadIdx.x) * V;
     round_fields f{0, 0, 0, 0};
     if (g0 + V <= a.G)
         f = round_fixed_body<N, V, WHAT, NT, true>(a, (uint32_t)g0, V);
     else if (g0 < a.G)
         f = round_fixed_body<N, V, WHAT, NT, false>(a, (uint32_t)g0, (int)(a.G - g0));
+    signal_started(a);          // any time while the launch runs: it only has to have started
     if constexpr ((WHAT & RQ_WHAT_VOTE) != 0) {
         if (a.elected_bits) pack_elected<V>(f.elected, g0, a.G, a.elected_bits);
     }
@@ -752,7 +785,7 @@ __device__ __forceinline__ round_fields round_joint_body(const rq_round_args_t<T
                 const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
                 int32_t o[V];
                 ld_i32<V, NTL, FULL>(offp, valid, o);
-                const int32_t oend = *at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));
+                const int32_t oend = *(const RQ_GLOBAL int32_t *)at(reinterpret_cast<const int32_t *>(a.log_off), addr_of(a, g0 + valid));
 #pragma unroll
                 for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
                 off[V] = oend;
@@ -877,16 +910,24 @@ hipError_t launch_grid(K kernel, const rq_round_args_t<T> &a, uint32_t block, hi
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, a);
     return hipGetLastError();
 }
+template <typename K, typename T>
+hipError_t launch_grid_lead(K kernel, const rq_round_args_t<T> &a, uint32_t block, hipStream_t s) {
+    const uint32_t grid = (uint32_t)(((uint64_t)a.G + block - 1) / block);
+    const uint64_t stride = a.tile_bytes ? (a.tile_bytes | kStrideTiled) : (uint64_t)a.ld;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, a.G, block, stride,
+                       a.voter_term, a.voted_for, a.last_log_term, a.match, a.commit, a);
+    return hipGetLastError();
+}
 
 // plain: default cache policy for every access (only in builds with RQ_BUILD_PLAIN; a build
 // without them runs the streaming kernels instead -- the policy never changes a result).
 template <int N, int WHAT, typename T>
 hipError_t launch_fixed_policy(const rq_round_args_t<T> &a, bool plain, uint32_t block, hipStream_t s) {
 #ifdef RQ_BUILD_PLAIN
-    if (plain) return launch_grid(rq_round_fixed<N, 1, WHAT, false, T>, a, block, s);
+    if (plain) return launch_grid_lead(rq_round_fixed<N, 1, WHAT, false, T>, a, block, s);
 #endif
     (void)plain;
-    return launch_grid(rq_round_fixed<N, 1, WHAT, true, T>, a, block, s);
+    return launch_grid_lead(rq_round_fixed<N, 1, WHAT, true, T>, a, block, s);
 }
 
 template <int N, typename T>

@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def resources(src, extra=()):
     with tempfile.TemporaryDirectory() as tmp:
         r = subprocess.run(["hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+                            "-mllvm", "-amdgpu-kernarg-preload-count=16",        # as the Makefile builds
                             "-Rpass-analysis=kernel-resource-usage", *extra, "-c", src, "-o", os.path.join(tmp, "k.o")],
                            cwd=ROOT, capture_output=True, text=True)
         if r.returncode != 0:
