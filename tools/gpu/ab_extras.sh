@@ -1,7 +1,9 @@
 #!/bin/bash
-# GPU box: the driver-style bench line with every secondary figure, old library build against the in-tree one.
+# GPU box: the bench line with every secondary figure, another build of librq.so against the in-tree one.
+# usage: bash tools/gpu/ab_extras.sh <other library, relative to the repository>
 cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out
-for lib in ab/librq_old.so ""; do
+OTHER=${1:-ab/librq_old.so}
+for lib in "$OTHER" ""; do
   RQ_LIBRARY=${lib:+$GRAFT_REPO_ROOT/$lib} timeout -k 10 400 python bench.py --no-cpu-baseline --steps 200 --warmup 20 2>> gpurun_out/abx.err > gpurun_out/abx_${lib:+old}.json || exit 1
 done
 python - <<'PY'
