@@ -1,6 +1,7 @@
 package raft
 
 /*
+#include <stdlib.h>
 #include <string.h>
 #include "rq.h"
 */
@@ -102,6 +103,25 @@ func (e *rqEngine) fromDevice(dst, src unsafe.Pointer, bytes uint64) error {
 // prepare validates the descriptor once; launch then costs two arguments.
 func (im *residentImage) prepare() error {
 	return rqError(C.rq_plan_round(im.eng.h, &im.desc, &im.plan), "rq_plan_round")
+}
+
+// prepareRounds makes ONE prepared launch over several images (one per cluster
+// size in its own compact tiles, or several short batches): rq_plan_rounds. The
+// descriptors live in C memory for the duration of the call only.
+func (e *rqEngine) prepareRounds(descs []C.rq_round_desc) (*C.rq_plan, error) {
+	if len(descs) < 1 || len(descs) > C.RQ_MAX_SEGMENTS {
+		return nil, errors.New("rq_plan_rounds: 1..16 images")
+	}
+	bytes := C.size_t(len(descs)) * C.size_t(C.sizeof_rq_round_desc)
+	mem := (*C.rq_round_desc)(C.malloc(bytes))
+	if mem == nil {
+		return nil, errors.New("rq_plan_rounds: out of memory")
+	}
+	defer C.free(unsafe.Pointer(mem))
+	copy(unsafe.Slice(mem, len(descs)), descs)
+	var plan *C.rq_plan
+	rc := C.rq_plan_rounds(e.h, mem, C.uint32_t(len(descs)), &plan)
+	return plan, rqError(rc, "rq_plan_rounds")
 }
 
 // launch enqueues the round on the device's default stream and returns.
