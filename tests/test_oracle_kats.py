@@ -478,3 +478,38 @@ def test_batch_commit_rule_equals_per_node_append_entries_rpc():
         finally:
             c.close()
     assert {(True, False, True), (True, False, False), (False, False, False), (False, True, False)} <= seen
+
+
+def test_size_order_helpers_describe_the_batch_truthfully():
+    """synth.segment_table / split_by_size / reorder (host-side layout helpers of the one-launch
+    forms): the table covers [0, G) in 64-aligned steps and only calls a tile a size-n tile when all of
+    its groups are plain n-peer clusters; the per-size images together are the batch (the oracle on
+    each image equals the oracle on the whole); reordering permutes the oracle's decisions."""
+    from raft_amd import synth
+    for G, frac in ((1, 0.1), (64, 0.0), (4097, 0.1), (20000, 0.3)):
+        b = synth.gen_mixed(G, seed=9 + G, bucketed="size", joint_frac=frac)
+        first, kinds = synth.segment_table(b.old_mask, b.new_mask)
+        assert first[0] == 0 and first[-1] == G and len(first) == len(kinds) + 1 and len(kinds) <= 16
+        assert all(x % 64 == 0 for x in first[1:-1]) and all(first[i] < first[i + 1] for i in range(len(kinds)))
+        assert all(kinds[i] != kinds[i + 1] for i in range(len(kinds) - 1))
+        for lo, hi, k in zip(first[:-1], first[1:], kinds):
+            if k:
+                assert (b.old_mask[lo:hi] == (1 << k) - 1).all() and (b.new_mask[lo:hi] == (1 << k) - 1).all()
+        whole = o.fused_round(*b.fused_args(), G=G, old_mask=b.old_mask, new_mask=b.new_mask)
+        covered = 0
+        for k, lo, hi, sub in synth.split_by_size(b):
+            assert lo == covered and sub.G == hi - lo and sub.n == (k or b.n)
+            covered = hi
+            kw = {} if k else dict(old_mask=sub.old_mask, new_mask=sub.new_mask)
+            part = o.fused_round(*sub.fused_args(), G=sub.G, **kw)
+            for f in ("commit", "grant_mask", "stepdown_mask", "elected", "max_term", "status"):
+                assert np.array_equal(part[f], whole[f][lo:hi]), (G, k, f)
+        assert covered == G
+        order = np.random.default_rng(G).permutation(G)
+        r = synth.reorder(b, order)
+        moved = o.fused_round(*r.fused_args(), G=G, old_mask=r.old_mask, new_mask=r.new_mask)
+        for f in ("commit", "grant_mask", "elected", "status"):
+            assert np.array_equal(moved[f], whole[f][order]), f
+    # an order that needs more than 16 segments has no table
+    b = synth.gen_mixed(5000, seed=3, bucketed=False, joint_frac=0.0)
+    assert synth.segment_table(b.old_mask, b.new_mask) in (None, ([0, 5000], [0]))
