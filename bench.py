@@ -40,6 +40,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0           # MI355X HBM3E spec peak
+METRIC = "quorum decisions/sec at 1M groups x 5 peers (1/8 GPU); % of HBM peak"
+UNIT = "decisions/s"
 # the round kernels and their argument structure (rq_kernels.h also declares the other kernels' arguments)
 KERNEL_SOURCES = ("raft_amd/csrc/rq_round_impl.h", "raft_amd/csrc/rq_kernels.h:rq_round_args_t")
 
@@ -219,9 +221,9 @@ def launch_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out,
                                       start_new_session=True))
     rc, line = supervise(procs, args.launcher_timeout)
-    if rc == 0:
-        sys.stdout.write(line.decode())
-        sys.stdout.flush()
+    # a failed run relays what rank 0 still wrote: nothing, or the watchdog's line marked "valid": false
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
     sys.exit(rc)
 
 
@@ -233,9 +235,9 @@ class Watchdog:
     or collective then costs a minute and leaves a diagnosis instead of running into the
     caller's time limit with nothing."""
 
-    def __init__(self, limit_s, describe=None, out=None, exit_fn=None):
+    def __init__(self, limit_s, describe=None, out=None, exit_fn=None, last_words=None):
         import threading
-        self.limit_s, self.describe = float(limit_s), describe
+        self.limit_s, self.describe, self.last_words = float(limit_s), describe, last_words
         self.out = out or sys.stderr
         self.exit_fn = exit_fn or (lambda code: os._exit(code))
         self.armed, self.last, self.where, self.beats = False, time.monotonic(), "start", 0
@@ -276,6 +278,11 @@ class Watchdog:
                     for tid, frame in sys._current_frames().items():
                         self.out.write("Thread 0x%x:\n%s" % (tid, "".join(traceback.format_stack(frame))))
                 self.out.flush()
+                if self.last_words is not None:
+                    try:
+                        self.last_words()
+                    except Exception as e:
+                        self.out.write("bench.py watchdog: last words failed: %r\n" % (e,))
                 self.exit_fn(3)
 
 
@@ -692,15 +699,42 @@ def main():
     eng = DeviceEngine(dev_index)
     exchange = use_dist and not args.no_exchange
     state = {}                                   # what the watchdog reports
-    dog = Watchdog(args.watchdog_seconds, lambda: dict(
-        step=state.get("step"), phase=state.get("phase"), exchange=state["ex"].debug_state() if state.get("ex") else None))
+
+    def degraded_line():
+        """The watchdog's last words on rank 0: if the steps without the exchange had already been
+        timed when the run got stuck, their figure goes out as a line marked invalid (this rank's
+        clock only, nothing sent between ranks), so that a wedged exchange still leaves the
+        kernels' figure behind.  The exit code stays 3."""
+        c = state.get("compute_only_local")
+        if rank != 0 or c is None:
+            return
+        line = {"metric": METRIC, "value": c["G"] * world * c["steps"] / c["wall"], "unit": UNIT, "n_gpus": world,
+                "steps": c["steps"], "warmup": args.warmup, "ms_per_step": c["wall"] / c["steps"] * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32", "data": "synthetic",
+                "valid": False,
+                "degraded": "the run stopped making progress in phase %r; value and ms_per_step are rank 0's own clock "
+                            "over the steps WITHOUT the summary exchange, timed before it" % (state.get("phase"),),
+                "config": {"workload": c["workload"], "groups_per_gpu": c["G"], "total_groups": c["G"] * world},
+                "roofline": {"bound": "hbm", "kernel_ms": c["kernel_ms"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "achieved": c["bytes_per_group"] * c["G"] / (c["kernel_ms"] * 1e-3) / 1e9,
+                             "frac": c["bytes_per_group"] * c["G"] / (c["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                             "traffic": None}}
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    # rank 0 gives up a little earlier than the others: a run that is stuck is stuck on every rank
+    # within one exchange period, and rank 0 is the one with last words to say before the launcher,
+    # seeing the first rank fail, ends the rest
+    dog = Watchdog(args.watchdog_seconds if rank == 0 or args.watchdog_seconds <= 0 else args.watchdog_seconds * 1.25 + 2,
+                   lambda: dict(
+        step=state.get("step"), phase=state.get("phase"), exchange=state["ex"].debug_state() if state.get("ex") else None),
+        last_words=degraded_line)
     hang_rank, hang_step = (int(x) for x in os.environ.get("RQ_BENCH_INJECT_HANG", "-1:-1").split(":"))
 
     def measure(G, S, steps, warmup, preheat_rotations, label, rounds_per_exchange=None):
         """Build S rotating input/output sets of G groups on this rank, run the untimed rotations,
-        then time `steps` steps with the exchange (if any) and -- with more than one rank or a forced
-        exchange -- the same steps again without it, so that one invocation separates the kernels'
-        scaling from the cost of the exchange."""
+        then -- with more than one rank or a forced exchange -- time `steps` steps without the
+        exchange, and then the same steps with it (the figure of the line), so that one invocation
+        separates the kernels' scaling from the cost of the exchange."""
         n = args.peers
         R = max(1, min(rounds_per_exchange or args.rounds_per_exchange, S))
         while S % R:
@@ -770,7 +804,7 @@ def main():
             dog.beat("step")
             if debug:
                 sys.stderr.write("rank %d step %d\n" % (rank, i)); sys.stderr.flush()
-            if rank == hang_rank and i == hang_step and state.get("phase") == label + ":timed":
+            if rank == hang_rank and i == hang_step and state.get("phase") == label + ":timed" and (with_ex or ex is None):
                 time.sleep(1e6)                  # test hook: this rank never gets to its next collective
             if x is not None and s % R == 0:
                 x.begin(s // R)                  # the slot's previous all-gather must be done
@@ -782,6 +816,8 @@ def main():
                 eng.vote_tally(sets[s], variant=args.variant)
             if x is not None and s % R == 0:
                 x.round_started((s // R - 1) % depth)
+            elif ex is not None and s % R == 0:
+                ex.launch_counted((s // R - 1) % depth)   # the launch bumped the slot's signal word all the same
             if x is not None and s % R == R - 1:
                 x.filled(s // R)                     # R rounds of summaries in one collective
                 if consumer is not None:
@@ -835,18 +871,27 @@ def main():
         dog.arm(label + ":preheat")
         state["phase"] = label + ":preheat"
         preheat = S * max(1, preheat_rotations)
-        for i in range(preheat):
+        res = dict(G=G, S=S, R=R, ex=ex, consumer=consumer, sets=sets, host_batches=host_batches, verify_host=verify_host,
+                   bytes_per_group=bytes_per_group, workload=workload, preheat=preheat, escape_counter=escape_counter,
+                   compute_only=None)
+        if ex is not None:
+            # first the steps without the exchange (the launches still write their summaries into
+            # the exchange's buffers, nothing is sent): should the exchange get stuck afterwards,
+            # the kernels' own figure exists already and the watchdog can leave it behind
+            for i in range(preheat):
+                step(i, False)
+            fence(False)
+            cw, ck, _ = timed(False)
+            res["compute_only"] = dict(wall=cw, kernel_ms=ck)
+            if label == "main":
+                state["compute_only_local"] = dict(G=G, steps=steps, wall=cw, kernel_ms=ck, workload=workload,
+                                                   bytes_per_group=bytes_per_group)
+            state["phase"] = label + ":preheat with the exchange"
+        for i in range(preheat if ex is None else S * min(4, max(1, preheat_rotations))):
             step(i)
         fence()
         wall, kernel_ms, enq = timed(True)
-        res = dict(G=G, S=S, R=R, ex=ex, consumer=consumer, sets=sets, host_batches=host_batches, verify_host=verify_host,
-                   bytes_per_group=bytes_per_group, workload=workload, preheat=preheat, wall=wall, kernel_ms=kernel_ms,
-                   enqueue_s=enq, escape_counter=escape_counter, compute_only=None)
-        if ex is not None:
-            # the same steps without the exchange: the launches still write their summaries into
-            # the exchange's buffers, nothing is sent (the exchange is not used again afterwards)
-            cw, ck, _ = timed(False)
-            res["compute_only"] = dict(wall=cw, kernel_ms=ck)
+        res.update(wall=wall, kernel_ms=kernel_ms, enqueue_s=enq)
         dog.disarm()
         state["phase"] = label + ":done"
         return res
@@ -925,8 +970,8 @@ def main():
     except (OSError, ValueError):
         pass
     line = {
-        "metric": "quorum decisions/sec at 1M groups x 5 peers (1/8 GPU); % of HBM peak",
-        "value": value, "unit": "decisions/s", "n_gpus": world, "steps": args.steps,
+        "metric": METRIC,
+        "value": value, "unit": UNIT, "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": wall / args.steps * 1e3,
         "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
         "dtype": "int64" if args.layout == "i64" else "int32", "data": "synthetic",

@@ -218,6 +218,12 @@ class SummaryExchange:
             self._filled[slot] = False
             self.exchange(slot, _after_signal=self._launched[slot])
 
+    def launch_counted(self, slot):
+        """A launch carrying start_signal(slot) has been enqueued by a caller that is not
+        exchanging right now: the word it bumps keeps in step with the host's count."""
+        if self.fence == "signal":
+            self._launched[slot] += 1
+
     def flush(self):
         """Issue the exchange of every slot that is filled and still waits for a
         following launch (the end of a run), fenced with an event."""

@@ -39,9 +39,11 @@ def test_bench_gpus_2_starts_two_ranks():
 
 @pytest.mark.gpu
 def test_a_rank_that_stops_making_progress_ends_the_run_with_a_diagnosis():
-    """Rank 1 never reaches step 6 of the timed region (a wedged fence or collective looks like
-    this to its peers): within the watchdog's limit a rank reports where it was and what its exchange
-    was doing and exits with code 3; the launcher ends the other rank and fails, without a line."""
+    """Rank 1 never reaches step 6 of the timed steps with the exchange (a wedged fence or collective
+    looks like this to its peers): within the watchdog's limit a rank reports where it was and what
+    its exchange was doing and exits with code 3; the launcher ends the other rank and fails.  The
+    steps without the exchange had been timed by then: rank 0 leaves their figure behind in a line
+    marked invalid."""
     import time
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["RQ_BENCH_INJECT_HANG"] = "1:6"
@@ -49,8 +51,12 @@ def test_a_rank_that_stops_making_progress_ends_the_run_with_a_diagnosis():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
                         "--groups", "65536", "--steps", "16", "--warmup", "4", "--no-cpu-baseline", "--no-extras",
                         "--watchdog-seconds", "6"], capture_output=True, text=True, timeout=280, env=env)
-    assert p.returncode != 0 and not p.stdout.strip()
+    assert p.returncode != 0
     assert time.time() - t0 < 200
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert r["valid"] is False and "WITHOUT the summary exchange" in r["degraded"] and "main:timed" in r["degraded"]
+    assert r["n_gpus"] == 2 and r["steps"] == 16 and r["value"] > 0 and 0 < r["roofline"]["frac"] < 1
+    assert r["config"]["total_groups"] == 131072
     assert "watchdog: rank" in p.stderr and "made no progress" in p.stderr, p.stderr[-3000:]
     assert '"exchange"' in p.stderr and "launched_with_signal" in p.stderr or "exchange_pending" in p.stderr
     assert "rank(s) failed" in p.stderr
