@@ -283,7 +283,9 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  *               the same factor.  log_term_base ([G], may be NULL = 0) is added
  *               to group g's entries before the comparison with leader_term
  *               (the host keeps base[g] <= every resident term of the group
- *               and picks the narrowest width the differences fit).
+ *               and picks the narrowest width the differences fit).  log_term
+ *               is aligned to its entry width (else RQ_E_ARG); the lookup may read
+ *               the other bytes of the aligned 32-bit word an entry lies in.
  *   log_base    [G], may be NULL: the arena is a window, slot i of group g's
  *               slice holds log[log_base[g] + i], so a host may keep only the
  *               uncommitted suffix of every log on the device (entries at or
@@ -477,7 +479,7 @@ int rq_plan_destroy(rq_plan *p);
  * rq_append_check, plus
  *   flog_terms      entries in the follower-log arena (same guarantee as
  *                   log_terms above: RQ_ST_BAD_CSR instead of a stray read);
- *   flog_term_bits  width of one arena entry (0, 8, 16, 32 as above);
+ *   flog_term_bits  width of one arena entry (0, 8, 16, 32 as above; flog_term aligned to it);
  *   flog_term_base  [G] or NULL: added to the entries of all followers of group g;
  *   flog_base       [n][ld] or NULL: follower s keeps only log[flog_base[s] ...]
  *                   on the device (the suffix around nextIndex is all a

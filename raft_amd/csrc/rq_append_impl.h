@@ -254,6 +254,7 @@ hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, const rq_round
     if ((a.tile_bytes & 7u) || (a.out_tile_bytes & 7u) || ((a.tile_bytes != 0) != (a.out_tile_bytes != 0))) return hipErrorInvalidValue;
     const uint32_t tb = a.flog_term_bits;
     if (tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
+    if (reinterpret_cast<uintptr_t>(a.flog_term) & (tb / 8 - 1)) return hipErrorInvalidValue;   // load_term reads aligned entries
     const uint32_t block = 128;
     const dim3 grid((a.G + block - 1) / block), blk(block);
     const int clamp_ptrs = (a.leader_commit != nullptr) + (a.last_new_index != nullptr) + (a.follower_commit_io != nullptr);
@@ -272,6 +273,7 @@ hipError_t launch_append_check_impl(const rq_append_args_t<T> &a, const rq_round
             return hipErrorInvalidValue;
         const uint32_t rb = r.log_term_bits;
         if (rb != 8 && rb != 16 && rb != 32 && rb != 8 * sizeof(T)) return hipErrorInvalidValue;
+        if (reinterpret_cast<uintptr_t>(r.log_term) & (rb / 8 - 1)) return hipErrorInvalidValue;
     }
     const bool commit = commit_round != nullptr;
 #define RQ_APPEND_LAUNCH(N, TILED, CLAMP)                                                                        \

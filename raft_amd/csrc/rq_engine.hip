@@ -1023,6 +1023,8 @@ int rq_plan_rounds(rq_engine *e, const rq_round_desc *descs, uint32_t count, rq_
         p->image_n[i] = one.n; p->image_joint[i] = one.joint;
         one.args.nt_gather = rq_nt_gather(one.args);          // per image: each has its own arena
         one.args64.nt_gather = rq_nt_gather(one.args64);
+        if (one.args.log_term_start) one.args.log_off = nullptr;      // as rq_launch_round does: "no log_off" = "no arena lookup"
+        if (one.args64.log_term_start) one.args64.log_off = nullptr;
         if (wide) ((rq_round64_args *)p->many)[i] = one.args64; else ((rq_round_args *)p->many)[i] = one.args;
     }
     if (rc == RQ_OK) {

@@ -248,9 +248,8 @@ __device__ __forceinline__ void pack_elected(uint32_t field, uint64_t g0, uint32
 constexpr uint8_t kStLogOob = 0x01, kStEmptyLog = 0x02, kStBadCsr = 0x04;
 
 // The one dependent, data-indexed load of a round: log[N].TermNum.  Arena
-// entries are `bits` wide -- 8 or 16 (unsigned), 32 (signed) or the full element
-// -- a wave-uniform choice, so the switch is a scalar branch around loads of
-// different widths.  Its cache policy (a.nt_gather) is wave-uniform as well.
+// entries are `bits` wide -- 8 or 16 (unsigned), 32 (signed) or the full element,
+// a wave-uniform choice.  The cache policy (a.nt_gather) is wave-uniform as well.
 template <typename P>
 __device__ __forceinline__ P load_one(const P *pg, bool nt) {
     const RQ_GLOBAL P *p = (const RQ_GLOBAL P *)pg;
@@ -258,6 +257,8 @@ __device__ __forceinline__ P load_one(const P *pg, bool nt) {
     if (nt) return __builtin_nontemporal_load(p);
     return *p;
 }
+// A scalar branch around loads of the entry's own width: for callers that have
+// nothing else in flight when they look a term up (the AppendEntries batch).
 template <typename T>
 __device__ __forceinline__ T load_term(const void *arena, uint32_t bits, size_t idx, bool nt) {
     if (bits == 8) return (T)load_one(static_cast<const uint8_t *>(arena) + idx, nt);
@@ -266,6 +267,39 @@ __device__ __forceinline__ T load_term(const void *arena, uint32_t bits, size_t 
         if (bits == 32) return (T)load_one(static_cast<const int32_t *>(arena) + idx, nt);
     }
     return load_one(static_cast<const T *>(arena) + idx, nt);
+}
+// The rounds look the term up while their streamed planes are still arriving, and
+// there the branch above costs the overlap: before the narrow loads the compiler
+// waits for EVERY outstanding load (their address registers might be the target of
+// the other width's load, for all it can tell).  So entries of up to 32 bits are
+// fetched by one load instruction whatever their width -- the aligned 32-bit word
+// that holds the entry -- and term_of() cuts the entry out where the term is
+// consumed, late.  The word never leaves the page the entry is in; entries are
+// naturally aligned (checked at launch).
+template <typename T>
+struct term_word {
+    typename std::make_unsigned<T>::type raw;
+    uint32_t shift;
+};
+template <typename T>
+__device__ __forceinline__ term_word<T> load_term_word(const void *arena, uint32_t bits, size_t idx, bool nt) {
+    typedef typename std::make_unsigned<T>::type U;
+    if constexpr (sizeof(T) == 8) {
+        if (bits == 64) return term_word<T>{(U)load_one(static_cast<const T *>(arena) + idx, nt), 0u};
+    }
+    const uint32_t lg = bits == 8 ? 0u : bits == 16 ? 1u : 2u;
+    const uintptr_t at = reinterpret_cast<uintptr_t>(arena) + (idx << lg);
+    const uint32_t w = load_one(reinterpret_cast<const uint32_t *>(at & ~(uintptr_t)3), nt);
+    return term_word<T>{(U)w, (uint32_t)(at & 3u) * 8u};
+}
+template <typename T>
+__device__ __forceinline__ T term_of(term_word<T> w, uint32_t bits) {
+    if constexpr (sizeof(T) == 8) {
+        if (bits == 64) return (T)w.raw;
+    }
+    const uint32_t v = (uint32_t)w.raw >> w.shift;
+    if (bits == 32) return (T)(int32_t)v;
+    return (T)(v & (bits == 8 ? 0xFFu : 0xFFFFu));
 }
 
 // A group's slice [beg, end) of a CSR arena of `total` entries is usable when the
@@ -420,46 +454,28 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     constexpr bool DO_VOTE = (WHAT & RQ_WHAT_VOTE) != 0;
     const group_addr ga = addr_of(a, g0);
 
-    T mt[N][V], cm[V], lt[V], lb[V], tb[V], ts[V];
-    int32_t off[V + 1], ln[V];
+    T mt[N][V], cm[V], lt[V], lb[V], lbs[V], tb[V];
+    int32_t off[V + 1], ln[V], lns[V];
 #pragma unroll
-    for (int k = 0; k < V; k++) { lb[k] = 0; tb[k] = 0; ln[k] = 0; lt[k] = 0; ts[k] = 0; }
+    for (int k = 0; k < V; k++) { lb[k] = 0; lbs[k] = 0; tb[k] = 0; ln[k] = 0; lns[k] = 0; lt[k] = 0; }
     T vt[N][V], vf[N][V], ll[N][V], ct[V], ci[V];
     uint32_t st[V];
 #pragma unroll
     for (int k = 0; k < V; k++) st[k] = 0;
 
-    // ---- issue every streamed load up front: first the arrays whose pointers arrive with the
-    // wave (the kernel's leading arguments), then the ones named by the rest of the arguments ----
-    if constexpr (DO_VOTE) {
-#pragma unroll
-        for (int p = 0; p < N; p++) {
-            ld_i32<V, NTL, FULL>(at(a.voter_term, ga, p), valid, vt[p]);
-            ld_i32<V, NTL, FULL>(at(a.voted_for, ga, p), valid, vf[p]);
-            ld_i32<V, NTL, FULL>(at(a.last_log_term, ga, p), valid, ll[p]);
-        }
-    }
+    // ---- issue every streamed load up front.  First what the dependent log-term gather needs
+    // (matchIndex, commitIndex, the log's place in the arena): loads complete in the order they
+    // were issued, so the gather can go out while the vote planes are still on their way.  The
+    // first five arrays are also the ones whose pointers arrive with the wave (the kernel's
+    // leading arguments); the rest of the arguments names the others ----
+    const bool lookup = a.log_off != nullptr;       // uniform; the launcher clears log_off when log_term_start replaces the arena
     if constexpr (DO_COMMIT) {
 #pragma unroll
         for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(at(a.match, ga, p), valid, mt[p]);
         ld_i32<V, NTL, FULL>(at(a.commit, ga), valid, cm);
-    }
-    if constexpr (DO_VOTE) {
-        ld_i32<V, NTL, FULL>(at(a.cand_term, ga), valid, ct);
-        ld_i32<V, NTL, FULL>(at(a.cand_id, ga), valid, ci);
-    }
-    if constexpr (DO_COMMIT) {
-        if (a.log_term_start) {
-            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
-            ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
-            ld_i32<V, NTL, FULL>(at(a.log_term_start, ga), valid, ts);
 #pragma unroll
-            for (int k = 0; k <= V; k++) off[k] = 0;
-        } else {
-            ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
-            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
-            if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
-            if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
+        for (int k = 0; k <= V; k++) off[k] = 0;
+        if (lookup) {
             const int32_t *offp = at(reinterpret_cast<const int32_t *>(a.log_off), ga);
             int32_t o[V];
             ld_i32<V, NTL, FULL>(offp, valid, o);
@@ -469,6 +485,35 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 #pragma unroll
             for (int k = 0; k < V; k++) off[k] = k < valid ? o[k] : oend;
             off[V] = oend;
+            // what else the gather's address needs; these pointers come with the rest of the arguments
+            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lb);
+            if (a.log_len) ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, ln);
+        }
+    }
+    if constexpr (DO_VOTE) {
+#pragma unroll
+        for (int p = 0; p < N; p++) {
+            ld_i32<V, NTL, FULL>(at(a.voter_term, ga, p), valid, vt[p]);
+            ld_i32<V, NTL, FULL>(at(a.voted_for, ga, p), valid, vf[p]);
+        }
+    }
+    if constexpr (DO_VOTE) {
+#pragma unroll
+        for (int p = 0; p < N; p++) ld_i32<V, NTL, FULL>(at(a.last_log_term, ga, p), valid, ll[p]);
+        ld_i32<V, NTL, FULL>(at(a.cand_term, ga), valid, ct);
+        ld_i32<V, NTL, FULL>(at(a.cand_id, ga), valid, ci);
+    }
+    const bool by_start = !lookup;
+    if constexpr (DO_COMMIT) {
+        if (lookup) {
+            ld_i32<V, NTL, FULL>(at(a.leader_term, ga), valid, lt);
+            if (a.log_term_base) ld_i32<V, NTL, FULL>(at(a.log_term_base, ga), valid, tb);
+        } else {
+            // no gather to hurry, so nothing here was worth waiting for the arguments.  Registers of
+            // their own: a second load into lb / ln down here would make the gather above wait for it
+            if (a.log_base) ld_i32<V, NTL, FULL>(at(a.log_base, ga), valid, lbs);
+            ld_i32<V, NTL, FULL>(at(reinterpret_cast<const int32_t *>(a.log_len), ga), valid, lns);
+            // log_term_start itself is read by the load that is the gather in the other mode (below)
         }
     }
 
@@ -479,9 +524,10 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
     const group_addr gvo = (const void *)a.voter_term_out == (const void *)a.voter_term ? ga : go;
 
     // ---- commit: quorum index, then the dependent log-term gather ----
-    T nq[V], gt[V];
+    T nq[V];
+    term_word<T> gw[V];
+    size_t ask[V];
     bool adv[V], inb[V];
-    const bool by_start = a.log_term_start != nullptr;         // uniform: no arena lookup
     if constexpr (DO_COMMIT) {
 #pragma unroll
         for (int k = 0; k < V; k++) {
@@ -489,16 +535,28 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 #pragma unroll
             for (int p = 0; p < N; p++) s[p] = mt[p][k];
             nq[k] = quorum_index<N>(s);
-            const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
-            const bool csr = by_start || (a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms));
-            const uint32_t len = a.log_len ? (uint32_t)ln[k] : end - beg;
-            const U wi = window_slot(nq[k], lb[k]);
             adv[k] = (k < valid) && nq[k] > cm[k];
-            inb[k] = csr && wi < (U)len;
-            st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
-            gt[k] = 0;
-            if (!by_start && adv[k] && inb[k])
-                gt[k] = (T)((U)load_term<T>(a.log_term, a.log_term_bits, (size_t)beg + (size_t)wi, a.nt_gather != 0) + (U)tb[k]);
+            if (lookup) {
+                const uint32_t beg = (uint32_t)off[k], end = (uint32_t)off[k + 1];
+                const bool csr = a.log_len ? span_ok(beg, (uint32_t)ln[k], a.log_terms) : slice_ok(beg, end, a.log_terms);
+                const uint32_t len = a.log_len ? (uint32_t)ln[k] : end - beg;
+                const U wi = window_slot(nq[k], lb[k]);
+                inb[k] = csr && wi < (U)len;
+                st[k] |= (k < valid && !csr) ? kStBadCsr : 0;
+                ask[k] = (adv[k] && inb[k]) ? (size_t)beg + (size_t)wi : (size_t)0;
+            } else {
+                inb[k] = window_slot(nq[k], lbs[k]) < (U)(uint32_t)lns[k];
+                ask[k] = 0;
+            }
+            // Every lane of every launch issues this last load: the looked-up term; without an arena
+            // the group's log_term_start; word 0 of the commit plane when a lane has nothing to ask
+            // (result unused).  A branch around it, scalar or per lane, would make the vote below
+            // wait for all outstanding loads, this one included, where it now waits for all but it.
+            const bool can = lookup && a.log_terms != 0;
+            const void *src = can ? a.log_term : (const void *)a.commit;
+            if (by_start && k < valid) src = at(a.log_term_start, ga) + k;
+            gw[k] = load_term_word<T>(src, can ? a.log_term_bits : by_start ? 8u * (uint32_t)sizeof(T) : 32u, ask[k],
+                                      by_start || (can && a.nt_gather != 0));
         }
     }
 
@@ -540,7 +598,9 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
         T co[V];
 #pragma unroll
         for (int k = 0; k < V; k++) {
-            const bool hit = by_start ? nq[k] >= ts[k] : gt[k] == lt[k];     // the looked-up term is consumed here, late
+            // the looked-up term (or log_term_start) is consumed here, late
+            const T got = term_of<T>(gw[k], by_start ? 8u * (uint32_t)sizeof(T) : a.log_term_bits);
+            const bool hit = by_start ? nq[k] >= got : (T)((U)got + (U)tb[k]) == lt[k];
             co[k] = (adv[k] && inb[k] && hit) ? nq[k] : cm[k];
             st[k] |= (adv[k] && !inb[k]) ? kStLogOob : 0;
             if (k < valid) ch_field |= (uint32_t)(co[k] != cm[k]) << k;
@@ -556,23 +616,22 @@ __device__ __forceinline__ round_fields round_fixed_body(const rq_round_args_t<T
 }
 
 // The arguments a wave needs before it can issue its first loads -- the group count, the block
-// size, the layout's stride and the five arrays that make up most of the traffic -- travel as
-// leading scalar kernel arguments, 14 dwords: the build preloads those into SGPRs at wave launch
-// (kernarg preload), so the streamed loads go out at once while the rest of the argument
-// structure is still on its way from memory.  stride: bit 63 set = 64-group tiles of
+// size, the layout's stride, the three arrays the log-term lookup depends on and the first two
+// vote planes -- travel as leading scalar kernel arguments, 14 dwords: the build preloads those
+// into SGPRs at wave launch (kernarg preload), so the streamed loads go out at once while the
+// rest of the argument structure is still on its way from memory.  stride: bit 63 set = 64-group tiles of
 // (stride & ~bit 63) bytes, else the plane stride ld in elements.
 constexpr uint64_t kStrideTiled = 1ull << 63;
 template <int N, int V, int WHAT, bool NT, typename T>
 __global__ __launch_bounds__(kBlock) void rq_round_fixed(uint32_t G, uint32_t block, uint64_t stride,
+                                                         const T *match, const T *commit, const uint32_t *log_off,
                                                          const T *voter_term, const T *voted_for,
-                                                         const T *last_log_term, const T *match, const T *commit,
                                                          rq_round_args_t<T> rest) {
     rq_round_args_t<T> a = rest;
     a.G = G;
     a.tile_bytes = (stride & kStrideTiled) ? (stride & ~kStrideTiled) : 0;
     a.ld = (stride & kStrideTiled) ? 0u : (uint32_t)stride;
-    a.match = match; a.voter_term = voter_term; a.voted_for = voted_for; a.last_log_term = last_log_term;
-    a.commit = commit;
+    a.match = match; a.commit = commit; a.log_off = log_off; a.voter_term = voter_term; a.voted_for = voted_for;
     const uint64_t g0 = ((uint64_t)blockIdx.x * block + threadIdx.x) * V;
     round_fields f{0, 0, 0, 0};
     if (g0 + V <= a.G)
@@ -915,7 +974,7 @@ hipError_t launch_grid_lead(K kernel, const rq_round_args_t<T> &a, uint32_t bloc
     const uint32_t grid = (uint32_t)(((uint64_t)a.G + block - 1) / block);
     const uint64_t stride = a.tile_bytes ? (a.tile_bytes | kStrideTiled) : (uint64_t)a.ld;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, s, a.G, block, stride,
-                       a.voter_term, a.voted_for, a.last_log_term, a.match, a.commit, a);
+                       a.match, a.commit, a.log_off, a.voter_term, a.voted_for, a);
     return hipGetLastError();
 }
 
@@ -1080,6 +1139,7 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
     const uint32_t tb = args.log_term_bits;
     if ((what & RQ_WHAT_COMMIT) && tb != 8 && tb != 16 && tb != 32 && tb != 8 * sizeof(T)) return hipErrorInvalidValue;
     if (!aligned_to(args.start_signal, 8)) return hipErrorInvalidValue;
+    if ((what & RQ_WHAT_COMMIT) && !aligned_to(args.log_term, tb / 8)) return hipErrorInvalidValue;   // load_term reads aligned entries
     if ((what & RQ_WHAT_COMMIT) && args.log_term_start && !args.log_len) return hipErrorInvalidValue;
     if (variant & ~(RQ_VAR_PLAIN | 0xF00)) return hipErrorInvalidValue;
     const int bsel = (variant >> 8) & 0xF;
@@ -1093,6 +1153,7 @@ hipError_t launch_round_impl(const rq_round_args_t<T> &args, uint32_t n, bool jo
 #endif
     rq_round_args_t<T> a = args;
     a.nt_gather = rq_nt_gather(args);
+    if (a.log_term_start) a.log_off = nullptr;      // the kernels take "no log_off" for "no arena lookup"
     if (segs) {
         // Groups ordered by size in an image of n planes; member masks are needed only by
         // segments of kind 0 (without masks those take all n slots as their one configuration).
@@ -1154,6 +1215,7 @@ hipError_t launch_rounds_impl(const rq_round_args_t<T> *args, const uint32_t *n,
     for (uint32_t i = 0; i < count; i++) {
         const rq_round_args_t<T> &a = args[i];
         if (a.G > 0x7FFFFFFFu || (a.ld < a.G && !a.tile_bytes)) return hipErrorInvalidValue;
+        if ((what & RQ_WHAT_COMMIT) && !aligned_to(a.log_term, a.log_term_bits / 8)) return hipErrorInvalidValue;
         const bool fixed = !joint[i] && n[i] >= 1 && n[i] <= 9;
         if (!fixed && (a.m < 1 || a.m > 16 || (a.old_mask == nullptr) != (a.new_mask == nullptr))) return hipErrorInvalidValue;
         sb.first_group[i] = 0; sb.end_group[i] = a.G;

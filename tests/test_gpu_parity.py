@@ -1361,6 +1361,48 @@ def test_narrow_log_term_arena(dev, kind):
 
 
 @pytest.mark.parametrize("kind", ["fixed", "joint", "wide"])
+def test_log_term_arena_at_any_entry_aligned_address(dev, kind):
+    """Narrow arena entries are cut out of the aligned 32-bit word they lie in: the arena may
+    start at any address that is a multiple of its entry width (every byte offset for 8-bit
+    entries, the first and the last entries of the arena included), and one that is not is
+    refused (raft.go:151 is the lookup)."""
+    import torch
+    from raft_amd.device import DeviceBatch, RqError
+    G = 20011
+    if kind == "joint":
+        b = synth.gen_mixed(G, seed=21)
+        kw = dict(old_mask=b.old_mask, new_mask=b.new_mask)
+    else:
+        b = synth.gen_fused(G, 5, seed=21)
+        kw = {}
+    exp = o.fused_round(*b.fused_args(), G=G, **kw)
+    assert (exp["commit"] != b.commit[:G]).sum() > G // 10
+    batch = synth.widen(b)[0] if kind == "wide" else b
+    for bits, step in ((8, 1), (16, 2), (32, 4)):
+        if kind != "wide" and bits == 32:
+            continue
+        for off in range(0, 8, step):
+            db = DeviceBatch(batch, log_term_bits=bits)
+            arena = db.t["log_term"]
+            raw = arena.view(torch.uint8).reshape(-1)
+            moved = torch.full((raw.numel() + 16,), 0xEE, dtype=torch.uint8, device=raw.device)
+            moved[off:off + raw.numel()] = raw
+            db.t["log_term"] = moved[off:off + raw.numel()].view(arena.dtype)
+            assert db.t["log_term"].data_ptr() % 8 == off
+            dev.fused_round(db)
+            res = db.results()
+            assert np.array_equal(res["commit"], exp["commit"]), (kind, bits, off)
+            assert np.array_equal(res["status"], exp["status"]), (kind, bits, off)
+        if bits > 8:
+            db = DeviceBatch(batch, log_term_bits=bits)
+            raw = db.t["log_term"].view(torch.uint8).reshape(-1)
+            moved = torch.zeros(raw.numel() + 16, dtype=torch.uint8, device=raw.device)
+            db.t["log_term"] = moved[1:1 + raw.numel()]
+            with pytest.raises(RqError):
+                dev.fused_round(db)
+
+
+@pytest.mark.parametrize("kind", ["fixed", "joint", "wide"])
 def test_bad_log_offsets_are_a_status_bit_not_a_fault(dev, kind):
     """Device launches cannot validate log_off on the host.  Offsets that run
     backwards or point past the arena (log_terms) must not be dereferenced: the
