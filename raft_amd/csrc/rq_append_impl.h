@@ -112,8 +112,9 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     const size_t gT = append_index<TILED, T>(a.tile_bytes, ld, g, 0);
     const T lt = __builtin_nontemporal_load(gptr(a.leader_term + gT));
     const T tbase = a.flog_term_base ? __builtin_nontemporal_load(gptr(a.flog_term_base + gT)) : (T)0;
-    uint32_t act = a.active_mask ? (uint32_t)gptr(a.active_mask)[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)] : 0xFFFFu;
-    act &= n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
+    // without a mask nothing below waits for a load before the slots' own loads go out
+    uint32_t act = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
+    if (a.active_mask) act &= (uint32_t)gptr(a.active_mask)[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)];
     const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
     constexpr bool clamp = CLAMP;
     const T lc = clamp ? __builtin_nontemporal_load(gptr(a.leader_commit + gT)) : (T)0;
@@ -153,7 +154,16 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
 #pragma unroll
         for (int p = 0; p < L; p++) mv[p] = p < NMAX ? mi[p] : (T)0;
     }
+    // The followers' log[prevLogIndex].TermNum (raft.go:151), one lookup per slot.  Every slot of
+    // every lane issues one -- the same load instruction whatever the entry width, entry 0 (or,
+    // without an arena, word 0 of the leader terms) for a slot with nothing to ask, result unused --
+    // and the words are cut where the terms are compared: branches around the loads, per width or
+    // per lane, made each lookup wait for the one before it, four memory latencies in a row.
     uint32_t reach = 0, inb = 0, bad = 0;
+    const bool arena = a.flog_terms != 0;
+    const void *tsrc = arena ? a.flog_term : (const void *)a.leader_term;
+    const uint32_t tbits = arena ? a.flog_term_bits : 32u;
+    term_word<T> tw[NMAX];
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
         const bool on = (act >> p) & 1u;
@@ -164,10 +174,10 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
         reach |= (uint32_t)rch << p;
         inb |= (uint32_t)in << p;
         bad |= (uint32_t)(on && !csr) << p;
-        tg[p] = 0;
-        if (rch && in)
-            tg[p] = (T)((U)load_term<T>(a.flog_term, a.flog_term_bits, (size_t)o0[p] + (size_t)wi, true) + (U)tbase);
+        tw[p] = load_term_word<T>(tsrc, tbits, (rch && in) ? (size_t)o0[p] + (size_t)wi : (size_t)0, arena);
     }
+#pragma unroll
+    for (int p = 0; p < NMAX; p++) tg[p] = (T)((U)term_of<T>(tw[p], tbits) + (U)tbase);
     // pure outputs live in their own tile block; follower terms updated in place stay with the inputs
     const uint64_t out_tile = a.out_tile_bytes;
     const uint64_t fo_tile = (const void *)a.follower_term_out == (const void *)a.follower_term ? a.tile_bytes : out_tile;
@@ -205,7 +215,7 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     if (a.status_out) gptr(a.status_out)[append_index<TILED, uint8_t>(out_tile, ld, g, 0)] = (uint8_t)st;
     if constexpr (COMMIT) {
         // the round's own inputs are read here, after the batch's stores: issued with the batch's
-        // planes they cost 40 registers and half the resident waves
+        // planes they cost 11 registers and two of the eight resident waves (measured 3 % slower)
         const group_addr rga = addr_of(r, g);
         group_addr rgo = rga;                     // the round's outputs: their own tile block unless in place
         if (r.tile_bytes) rgo.tile_off = (size_t)(g >> 6) * r.out_tile_bytes;
