@@ -285,7 +285,7 @@ int rq_download(rq_engine *e, int32_t *commit_out, int32_t *voter_term_out,
  *               (the host keeps base[g] <= every resident term of the group
  *               and picks the narrowest width the differences fit).  log_term
  *               is aligned to its entry width (else RQ_E_ARG); the lookup may read
- *               the other bytes of the aligned 32-bit word an entry lies in.
+ *               the other bytes of the aligned word (of the layout's element size) an entry lies in.
  *   log_base    [G], may be NULL: the arena is a window, slot i of group g's
  *               slice holds log[log_base[g] + i], so a host may keep only the
  *               uncommitted suffix of every log on the device (entries at or

@@ -271,11 +271,11 @@ __device__ __forceinline__ T load_term(const void *arena, uint32_t bits, size_t 
 // The rounds look the term up while their streamed planes are still arriving, and
 // there the branch above costs the overlap: before the narrow loads the compiler
 // waits for EVERY outstanding load (their address registers might be the target of
-// the other width's load, for all it can tell).  So entries of up to 32 bits are
-// fetched by one load instruction whatever their width -- the aligned 32-bit word
-// that holds the entry -- and term_of() cuts the entry out where the term is
-// consumed, late.  The word never leaves the page the entry is in; entries are
-// naturally aligned (checked at launch).
+// the other width's load, for all it can tell).  So entries of every width are
+// fetched by one load instruction whatever their width -- the aligned word (as wide
+// as the layout's element) that holds the entry -- and term_of() cuts the entry out
+// where the term is consumed, late.  The word never leaves the page the entry is
+// in; entries are naturally aligned (checked at launch).
 template <typename T>
 struct term_word {
     typename std::make_unsigned<T>::type raw;
@@ -283,23 +283,19 @@ struct term_word {
 };
 template <typename T>
 __device__ __forceinline__ term_word<T> load_term_word(const void *arena, uint32_t bits, size_t idx, bool nt) {
-    typedef typename std::make_unsigned<T>::type U;
-    if constexpr (sizeof(T) == 8) {
-        if (bits == 64) return term_word<T>{(U)load_one(static_cast<const T *>(arena) + idx, nt), 0u};
-    }
-    const uint32_t lg = bits == 8 ? 0u : bits == 16 ? 1u : 2u;
+    typedef typename std::make_unsigned<T>::type U;          // the word: as wide as the layout's element
+    const uint32_t lg = bits == 8 ? 0u : bits == 16 ? 1u : bits == 32 ? 2u : 3u;
     const uintptr_t at = reinterpret_cast<uintptr_t>(arena) + (idx << lg);
-    const uint32_t w = load_one(reinterpret_cast<const uint32_t *>(at & ~(uintptr_t)3), nt);
-    return term_word<T>{(U)w, (uint32_t)(at & 3u) * 8u};
+    const U w = load_one(reinterpret_cast<const U *>(at & ~(uintptr_t)(sizeof(U) - 1)), nt);
+    return term_word<T>{w, (uint32_t)(at & (sizeof(U) - 1)) * 8u};
 }
 template <typename T>
 __device__ __forceinline__ T term_of(term_word<T> w, uint32_t bits) {
-    if constexpr (sizeof(T) == 8) {
-        if (bits == 64) return (T)w.raw;
-    }
-    const uint32_t v = (uint32_t)w.raw >> w.shift;
-    if (bits == 32) return (T)(int32_t)v;
-    return (T)(v & (bits == 8 ? 0xFFu : 0xFFFFu));
+    typedef typename std::make_unsigned<T>::type U;
+    const U v = w.raw >> w.shift;
+    if (bits == 8 * sizeof(T)) return (T)v;
+    if (bits == 32) return (T)(int32_t)(uint32_t)v;          // int32 entries of the wide layout
+    return (T)(v & (U)(bits == 8 ? 0xFFu : 0xFFFFu));
 }
 
 // A group's slice [beg, end) of a CSR arena of `total` entries is usable when the
