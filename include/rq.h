@@ -221,7 +221,10 @@ int rq_follower_clamp(rq_engine *e, uint64_t count, const int32_t *leader_commit
  * n_new, next = match + 1; rejected at the log check -> next = max(next-1, 1);
  * rejected for a stale term -> unchanged.
  * active_mask ([G], bit p; NULL = all n slots) selects the slots that receive
- * an RPC this round; other slots are left untouched.  Follower logs are one
+ * an RPC this round; other slots keep their values (arrays updated in place may
+ * be rewritten with what they held, and a follower_term_out that is not
+ * follower_term itself either keeps its old content there or receives a copy of
+ * follower_term: whole rows are written wherever some group of a wave uses the slot).  Follower logs are one
  * CSR arena indexed by slot id: flog_term[flog_off[s] .. flog_off[s+1]),
  * flog_off has n*ld + 1 entries.  n_new, match_index_io, next_index_io and
  * status_out may be NULL. */

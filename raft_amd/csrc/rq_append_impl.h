@@ -114,7 +114,19 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     const T tbase = a.flog_term_base ? __builtin_nontemporal_load(gptr(a.flog_term_base + gT)) : (T)0;
     // without a mask nothing below waits for a load before the slots' own loads go out
     uint32_t act = n >= 16 ? 0xFFFFu : ((1u << n) - 1u);
-    if (a.active_mask) act &= (uint32_t)gptr(a.active_mask)[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)];
+    // wact: the slots SOME lane of the wave sends an RPC to.  Those are loaded and stored by every
+    // lane (a lane without an RPC for the slot writes back what it read): rows with holes -- every
+    // plane has them when each group leaves out its own leader's slot -- would be partial writes,
+    // which the memory turns into a read and a write each.  Slots no lane uses are skipped whole.
+    uint32_t wact = act;
+    if (a.active_mask) {
+        act &= (uint32_t)gptr(a.active_mask)[append_index<TILED, uint16_t>(a.tile_bytes, ld, g, 0)];
+        wact = 0;
+#pragma unroll
+        for (int p = 0; p < NMAX; p++)
+            if (__ballot((act >> p) & 1u) != 0ull) wact |= 1u << p;
+        wact = __builtin_amdgcn_readfirstlane(wact);
+    }
     const bool upd = a.match_index_io != nullptr || a.next_index_io != nullptr;
     constexpr bool clamp = CLAMP;
     const T lc = clamp ? __builtin_nontemporal_load(gptr(a.leader_commit + gT)) : (T)0;
@@ -123,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
         ft[p] = pi[p] = pt[p] = nn[p] = mi[p] = fb[p] = fc[p] = li[p] = 0; ni[p] = 1; o0[p] = o1[p] = 0;
-        if ((act >> p) & 1u) {
+        if ((wact >> p) & 1u) {
             const size_t s = append_index<TILED, T>(a.tile_bytes, ld, g, p);
             const size_t so = append_index<TILED, uint32_t>(a.tile_bytes, ld, g, p);
             ft[p] = __builtin_nontemporal_load(gptr(a.follower_term + s));
@@ -184,14 +196,15 @@ __global__ __launch_bounds__(kBlock) void rq_append_check_kernel(rq_append_args_
     uint32_t ok = 0, sd = 0, st = bad ? kStBadCsr : 0;
 #pragma unroll
     for (int p = 0; p < NMAX; p++) {
-        if (!((act >> p) & 1u)) continue;
+        if (!((wact >> p) & 1u)) continue;
         const size_t s = append_index<TILED, T>(a.tile_bytes, ld, g, p);
-        const bool rch = (reach >> p) & 1u, in = (inb >> p) & 1u;
+        const bool on = (act >> p) & 1u;
+        const bool rch = (reach >> p) & 1u, in = (inb >> p) & 1u;          // rch implies on
         const bool success = rch && in && tg[p] == pt[p];
-        sd |= (uint32_t)(lt > ft[p]) << p;
+        sd |= (uint32_t)(on && lt > ft[p]) << p;
         ok |= (uint32_t)success << p;
         st |= (rch && !in) ? kStLogOob : 0;
-        __builtin_nontemporal_store(tmax(ft[p], lt), gptr(a.follower_term_out + append_index<TILED, T>(fo_tile, ld, g, p)));
+        __builtin_nontemporal_store(on ? tmax(ft[p], lt) : ft[p], gptr(a.follower_term_out + append_index<TILED, T>(fo_tile, ld, g, p)));
         if (upd) {
             T m2 = mi[p], n2 = ni[p];
             if (success) { m2 = (T)((U)pi[p] + (U)nn[p]); n2 = (T)((U)m2 + (U)1); }

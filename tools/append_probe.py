@@ -2,7 +2,8 @@
 """The AppendEntries consistency batch alone, for profiling: 1M groups x 4 follower
 planes (no mask), 8-bit follower-log entries, 6 rotating sets, device-resident.
 
-    python tools/append_probe.py [launches=120] [term_bits=0] [tiles|planes] [clamp]
+    python tools/append_probe.py [launches=120] [term_bits=0] [tiles|planes] [clamp|-] [masked]
+("masked", planes only: 5 slot planes with every group's own leader slot masked out instead.)
 Prints microseconds per launch and the fraction of HBM peak (186 algorithmic
 bytes per group; with "clamp" the follower commit rule of raft.go:172-176 runs in the
 same launch: 12 more bytes per follower and 4 per group, 238)."""
@@ -22,7 +23,8 @@ launches = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 term_bits = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 tiled = not (len(sys.argv) > 3 and sys.argv[3] == "planes")
 clamp = len(sys.argv) > 4 and sys.argv[4] == "clamp"
-G, n, dev = 1 << 20, 4, torch.device("cuda", 0)
+masked = len(sys.argv) > 5 and sys.argv[5] == "masked"
+G, n, dev = 1 << 20, 5 if masked else 4, torch.device("cuda", 0)
 eng = DeviceEngine(0)
 sets = []
 for s in range(6):
@@ -41,6 +43,8 @@ for s in range(6):
                                "match_index", "next_index")}
     if clamp:
         t.update({k: up(b[k]) for k in ("leader_commit", "last_new_index", "follower_commit")})
+    if masked:
+        t["active_mask"] = up(b.active_mask.view(np.int16))
     t["flog_off"] = up(b.flog_off.view(np.int32))
     t["flog_term"] = up(enc)
     t["follower_term_out"] = torch.zeros_like(t["follower_term"])
@@ -68,6 +72,6 @@ torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / launches * 1e3
 alg = 44 * 4 + 4 + 2 + 2 + 2 + ((12 * 4 + 4) if clamp else 0)
 print("append_check%s 1M x 4 followers, %s, %d-bit entries: %.2f us per launch, %.1f %% of 8 TB/s (%d B per group)"
-      % (" + commit rule" if clamp else "", "64-group tiles" if tiled else "planes", sets[0]["_bits"], us,
+      % (" + commit rule" if clamp else "", "64-group tiles" if tiled else ("5 planes, leader's slot masked" if masked else "planes"), sets[0]["_bits"], us,
          100 * alg * G / (us * 1e-6) / 8e12, alg))
 eng.close()
