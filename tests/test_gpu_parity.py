@@ -1452,6 +1452,51 @@ def test_bad_log_offsets_are_a_status_bit_not_a_fault(dev, kind):
 
 
 @pytest.mark.parametrize("wide", [False, True])
+def test_follower_log_arena_at_any_entry_aligned_address(dev, wide):
+    """The AppendEntries batch cuts narrow follower-log entries out of the aligned word they lie
+    in, like the rounds (raft.go:151 is the lookup): any address that is a multiple of the entry
+    width serves, one that is not is refused."""
+    import torch
+    from raft_amd.device import encode_log_terms, RqError
+    dt, tdt = (np.int64, torch.int64) if wide else (np.int32, torch.int32)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+    G, n, ld = 9001, 4, 9024
+    b = synth.gen_append(G, n, seed=41, ld=ld)
+    args, kw = _append_args(b)
+    exp = o.append_check(*args, **kw)
+
+    def run(bits, off):
+        enc, ebits, _ = encode_log_terms(b.flog_term.astype(dt), bits=bits)
+        raw = up(enc).view(torch.uint8).reshape(-1)
+        moved = torch.full((raw.numel() + 16,), 0xEE, dtype=torch.uint8, device="cuda:0")
+        moved[off:off + raw.numel()] = raw
+        t = dict(active_mask=up(b.active_mask.view(np.int16)), follower_term=up(b.follower_term.astype(dt)),
+                 leader_term=up(b.leader_term.astype(dt)), prev_log_index=up(b.prev_log_index.astype(dt)),
+                 prev_log_term=up(b.prev_log_term.astype(dt)), n_new=up(b.n_new.astype(dt)),
+                 flog_off=up(b.flog_off.view(np.int32)), flog_term=moved[off:off + raw.numel()],
+                 follower_term_out=torch.zeros((n, ld), dtype=tdt, device="cuda:0"),
+                 success_mask=torch.zeros(G, dtype=torch.int16, device="cuda:0"),
+                 stepdown_mask=torch.zeros(G, dtype=torch.int16, device="cuda:0"),
+                 match_index=up(b.match_index.astype(dt)), next_index=up(b.next_index.astype(dt)),
+                 status=torch.zeros(G, dtype=torch.uint8, device="cuda:0"))
+        assert t["flog_term"].data_ptr() % 8 == off
+        dev.append_check(t, G, n, ld, flog_term_bits=ebits, flog_terms=enc.size, wide=wide)
+        torch.cuda.synchronize()
+        return t
+
+    for bits, step in ((8, 1), (16, 2)):
+        for off in range(0, 8, step):
+            t = run(bits, off)
+            assert np.array_equal(t["success_mask"].cpu().numpy().view(np.uint16), exp["success_mask"]), (bits, off)
+            assert np.array_equal(t["status"].cpu().numpy(), exp["status"]), (bits, off)
+            assert np.array_equal(t["match_index"].cpu().numpy()[:, :G], exp["match_index"][:, :G]), (bits, off)
+            assert np.array_equal(t["next_index"].cpu().numpy()[:, :G], exp["next_index"][:, :G]), (bits, off)
+    assert exp["success_mask"].any() and (exp["success_mask"] != b.active_mask).any()
+    with pytest.raises(RqError):
+        run(16, 1)
+
+
+@pytest.mark.parametrize("wide", [False, True])
 def test_append_check_windows_narrow_arenas_and_bad_offsets(dev, wide):
     """rq_append_check_dev with follower logs kept as windows (flog_base), in narrow
     entries with a per-group base term, and with broken offsets."""
