@@ -234,7 +234,9 @@ private:
     template <typename T> int RebuildT();
     template <typename T> int StepT(Report *report);
     template <typename T> int FlattenRow(uint32_t g, T *row, std::vector<T> &terms, LogShape *shape = nullptr) const;
-    template <typename T> void ApplyRow(uint32_t g, const T *row, uint64_t flags);
+    // groups whose row must go up again and groups with status bits are appended to the caller's lists
+    template <typename T> void ApplyRow(uint32_t g, const T *row, uint64_t flags, std::vector<uint32_t> &redo,
+                                        std::vector<GroupStatus> &flagged);
     LogShape ShapeOf(uint32_t g) const;
     bool wide_ = false;
     std::vector<Group> groups_;

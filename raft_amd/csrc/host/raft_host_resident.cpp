@@ -6,6 +6,7 @@
 #include "raft_host.hpp"
 
 #include <atomic>
+#include <thread>
 
 namespace raft {
 
@@ -72,6 +73,26 @@ struct ResidentDriver::Impl {
         device_allocs.clear(); host_allocs.clear();
     }
 };
+
+// The rows a step moves are independent of each other, and reading or writing one means
+// walking a handful of heap objects that are rarely in cache (a microsecond per row is cache
+// misses): from 512 rows on the walk is dealt to host threads, 256 rows or more each,
+// fn(first, last, worker) on disjoint row ranges.  Below that one call on the caller's thread.
+static uint32_t RowWorkers(uint32_t rows) {
+    const uint32_t by_rows = rows / 256;
+    const uint32_t cap = ParallelWorkers(1u << 20);       // the drivers' thread limit
+    return by_rows < 2 ? 1 : (by_rows < cap ? by_rows : cap);
+}
+template <typename F>
+static void ParallelOverRows(uint32_t rows, uint32_t workers, F fn) {
+    if (workers <= 1) { fn(0u, rows, 0u); return; }
+    std::vector<std::thread> pool;
+    pool.reserve(workers - 1);
+    auto bound = [&](uint32_t w) { return (uint32_t)((uint64_t)rows * w / workers); };
+    for (uint32_t w = 1; w < workers; w++) pool.emplace_back([&fn, &bound, w]() { fn(bound(w), bound(w + 1), w); });
+    fn(0u, bound(1), 0u);
+    for (std::thread &t : pool) t.join();
+}
 
 ResidentDriver::ResidentDriver(std::vector<Group> groups, uint32_t slots, int device)
     : groups_(std::move(groups)), slots_(slots), device_(device), dirty_mark_(groups_.size(), 0) {}
@@ -335,7 +356,8 @@ int ResidentDriver::RebuildT() {
 // One gathered row back into the objects: voters' terms and roles
 // (raft.go:219-221), the leader's commitIndex, BecomeLeader for a winner.
 template <typename T>
-void ResidentDriver::ApplyRow(uint32_t g, const T *row, uint64_t flags) {
+void ResidentDriver::ApplyRow(uint32_t g, const T *row, uint64_t flags, std::vector<uint32_t> &redo,
+                              std::vector<GroupStatus> &flagged) {
     Group &grp = groups_[g];
     const uint32_t stepdown = (uint32_t)(flags >> 16) & 0xFFFFu;
     const bool elected = ((flags >> 32) & 0xFFu) != 0;
@@ -351,7 +373,7 @@ void ResidentDriver::ApplyRow(uint32_t g, const T *row, uint64_t flags) {
             grp.Candidate->BecomeLeader();
             grp.Leader = grp.Candidate;
             grp.Candidate = nullptr;
-            MarkDirty(g);                 // new leader arrays, no candidate: the row goes up again
+            redo.push_back(g);            // new leader arrays, no candidate: the row goes up again
         }
     }
     if (leader_before) leader_before->commitIndex = row[0];
@@ -359,9 +381,9 @@ void ResidentDriver::ApplyRow(uint32_t g, const T *row, uint64_t flags) {
     // without leader arrays, so that later rounds do not advance commitIndex for a Follower
     if (grp.Leader && grp.Leader->nodeType != Leader) {
         grp.Leader = nullptr;
-        MarkDirty(g);
+        redo.push_back(g);
     }
-    if (status) flagged_.push_back(GroupStatus{g, status});
+    if (status) flagged.push_back(GroupStatus{g, status});
 }
 
 int ResidentDriver::Step(Report *report) {
@@ -401,11 +423,28 @@ int ResidentDriver::StepT(Report *report) {
             for (auto it = moved.rbegin(); it != moved.rend(); ++it) { I.off[it->g] = it->off; I.cap[it->g] = it->cap; }
             I.tail = tail_before;
         };
+        // Without an arena a row is self-contained (no slice to book), so the rows are flattened
+        // on several threads first; the pass below then only checks them, in order.
+        const uint32_t workers = I.by_start ? RowWorkers(r) : 1;
+        std::vector<LogShape> shapes;
+        std::vector<int> flat_rc;
+        if (workers > 1) {
+            shapes.resize(r);
+            flat_rc.assign(r, RQ_OK);
+            ParallelOverRows(r, workers, [&](uint32_t i0, uint32_t i1, uint32_t) {
+                std::vector<T> none;
+                for (uint32_t i = i0; i < i1; i++)
+                    flat_rc[i] = FlattenRow<T>(dirty_[i], rows + (size_t)i * words, none, &shapes[i]);
+            });
+        }
         for (uint32_t i = 0; i < r && !need_rebuild; i++) {
             const uint32_t g = dirty_[i];
             T *row = rows + (size_t)i * words;
             LogShape shape;
-            if (const int frc = FlattenRow<T>(g, row, terms, I.by_start ? &shape : nullptr)) { take_back(); return frc; }
+            if (workers > 1) {
+                if (flat_rc[i]) { take_back(); return flat_rc[i]; }
+                shape = shapes[i];
+            } else if (const int frc = FlattenRow<T>(g, row, terms, I.by_start ? &shape : nullptr)) { take_back(); return frc; }
             if (!mixed_ && groups_[g].Members.size() != n) { need_rebuild = true; break; }
             // a group that left the size its segment was launched under: the table is made afresh
             if (!I.tile_kind.empty() && I.tile_kind[g >> 6] && groups_[g].Members.size() != I.tile_kind[g >> 6]) {
@@ -474,7 +513,17 @@ int ResidentDriver::StepT(Report *report) {
         RH_TRY(rq_copy_from_device(I.e, I.h_out, I.d_out, (uint64_t)r * (8 + (I.n + 2) * E)));
         const uint64_t *flags = (const uint64_t *)I.h_out;
         const T *orows = (const T *)(I.h_out + (uint64_t)r * 8);
-        for (uint32_t i = 0; i < r; i++) ApplyRow<T>(gids[i], orows + (size_t)i * (I.n + 2), flags[i]);
+        const uint32_t workers = RowWorkers(r);
+        std::vector<std::vector<uint32_t>> redo(workers);
+        std::vector<std::vector<GroupStatus>> flagged(workers);
+        ParallelOverRows(r, workers, [&](uint32_t i0, uint32_t i1, uint32_t w) {
+            for (uint32_t i = i0; i < i1; i++)
+                ApplyRow<T>(gids[i], orows + (size_t)i * (I.n + 2), flags[i], redo[w], flagged[w]);
+        });
+        for (uint32_t w = 0; w < workers; w++) {          // in row order, as one thread would have left them
+            for (uint32_t g : redo[w]) MarkDirty(g);
+            flagged_.insert(flagged_.end(), flagged[w].begin(), flagged[w].end());
+        }
         rep.changed += r;
         r = 0;
         return RQ_OK;

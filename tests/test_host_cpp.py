@@ -772,3 +772,59 @@ def test_resident_driver_without_a_log_arena():
                 c.l.rh_group_roles(c.h, g, lead, cand)
     finally:
         c.close()
+
+
+@pytest.mark.gpu
+def test_resident_driver_moves_many_rows_on_several_threads():
+    """Thousands of touched groups per step: the rows are flattened and applied on several host
+    threads (from 512 rows on).  Every object must still end where the oracle puts it, the
+    groups be reported in order, and a re-marked group (a new leader) go up again."""
+    G, n = 12000, 5
+    c, b = _build(G, n, seed=47, raft_shaped=True)
+    rng = np.random.default_rng(13)
+    try:
+        c.use_resident(0)
+        for g in range(G):
+            c.roles(g, *c.get_roles(g))
+        for it in range(4):
+            if it:
+                touched = rng.choice(G, 6000, replace=False)
+                for g in touched.tolist():
+                    lead, cand = c.get_roles(g)
+                    if lead >= 0:
+                        s = c.get(g, lead)
+                        new_len = s["logLen"] + int(rng.integers(0, 4))
+                        terms = [1 + (i * int(s["currentTerm"])) // new_len for i in range(new_len)]
+                        c.seed(g, lead, s["currentTerm"], s["votedFor"], h.LEADER, s["commitIndex"], terms)
+                        c.set_match(g, lead, [int(x) for x in rng.integers(0, new_len + 2, n)])
+                    if cand >= 0:
+                        s = c.get(g, cand)
+                        c.seed(g, cand, s["currentTerm"] + int(rng.integers(0, 2)), s["votedFor"], h.CANDIDATE, s["commitIndex"])
+            rc, f = c.flatten(log_cap=1 << 23)
+            assert rc == 0
+            exp = o.fused_round(f["match"], f["commit"], f["leader_term"], f["log_off"], f["log_term"],
+                                f["voter_term"], f["voted_for"], f["last_log_term"], f["cand_term"], f["cand_id"])
+            roles_before = [c.get_roles(g) for g in range(G)]
+            rc, rep = c.step_resident()
+            assert rc == 0
+            assert rep["rebuilt"] == (it == 0) and c.without_arena()
+            if it:
+                assert rep["uploaded"] >= 6000            # the touched rows + the ones the last step re-marked
+            moved = (exp.commit != f["commit"]) | (exp.stepdown_mask != 0) | (exp.elected != 0) | (exp.status != 0)
+            assert rep["changed"] == int(moved.sum())
+            if it == 1:
+                assert rep["changed"] >= 2048             # the apply side ran on several threads too
+            assert c.flagged() == [(int(g), int(exp.status[g])) for g in np.nonzero(exp.status)[0]]   # in group order
+            for g in range(G):
+                lead, cand = roles_before[g]
+                if cand >= 0:
+                    for p in range(n):
+                        assert c.get(g, p)["currentTerm"] == exp.voter_term[p, g], (it, g, p)
+                    assert (c.get_roles(g)[0] == cand) == bool(exp.elected[g]), (it, g)
+                if lead >= 0:
+                    assert c.get(g, lead)["commitIndex"] == exp.commit[g], (it, g)
+            for g in range(G):
+                lead, cand = c.get_roles(g)
+                c.l.rh_group_roles(c.h, g, lead, cand)
+    finally:
+        c.close()
