@@ -705,8 +705,17 @@ def main():
         timed when the run got stuck, their figure goes out as a line marked invalid (this rank's
         clock only, nothing sent between ranks), so that a wedged exchange still leaves the
         kernels' figure behind.  The exit code stays 3."""
+        if rank != 0:
+            return
+        done = state.get("main_line")
+        if done is not None:
+            # the figure of the line was complete; an additional leg got stuck: the line goes out as it
+            # was, with the leg's place saying so
+            done.setdefault("extra", {})["strong_8m"] = {"error": "the run stopped making progress in phase %r" % (state.get("phase"),)}
+            os.write(json_fd, (json.dumps(done) + "\n").encode())
+            return
         c = state.get("compute_only_local")
-        if rank != 0 or c is None:
+        if c is None:
             return
         line = {"metric": METRIC, "value": c["G"] * world * c["steps"] / c["wall"], "unit": UNIT, "n_gpus": world,
                 "steps": c["steps"], "warmup": args.warmup, "ms_per_step": c["wall"] / c["steps"] * 1e3,
@@ -728,7 +737,9 @@ def main():
                    lambda: dict(
         step=state.get("step"), phase=state.get("phase"), exchange=state["ex"].debug_state() if state.get("ex") else None),
         last_words=degraded_line)
-    hang_rank, hang_step = (int(x) for x in os.environ.get("RQ_BENCH_INJECT_HANG", "-1:-1").split(":"))
+    # test hook, "rank:step[:leg]": that rank never gets beyond that timed step (with the exchange) of that leg
+    hang = os.environ.get("RQ_BENCH_INJECT_HANG", "-1:-1").split(":")
+    hang_rank, hang_step, hang_leg = int(hang[0]), int(hang[1]), hang[2] if len(hang) > 2 else "main"
 
     def measure(G, S, steps, warmup, preheat_rotations, label, rounds_per_exchange=None):
         """Build S rotating input/output sets of G groups on this rank, run the untimed rotations,
@@ -804,7 +815,8 @@ def main():
             dog.beat("step")
             if debug:
                 sys.stderr.write("rank %d step %d\n" % (rank, i)); sys.stderr.flush()
-            if rank == hang_rank and i == hang_step and state.get("phase") == label + ":timed" and (with_ex or ex is None):
+            if (rank == hang_rank and i == hang_step and label == hang_leg and state.get("phase") == label + ":timed"
+                    and (with_ex or ex is None)):
                 time.sleep(1e6)                  # test hook: this rank never gets to its next collective
             if x is not None and s % R == 0:
                 x.begin(s // R)                  # the slot's previous all-gather must be done
@@ -1011,6 +1023,7 @@ def main():
     # 2 or 4 ranks: the sharded configuration itself (8M groups in total, block-partitioned) beside
     # the weak-scaling headline, every rank taking part
     if world in (2, 4) and not strong and args.workload == "fused" and not args.no_extras:
+        state["main_line"] = line                 # complete as far as the headline goes: the watchdog's last words from here on
         del sets, host_batches, verify_host
         m["sets"] = m["host_batches"] = m["verify_host"] = None
         if consumer is not None:
@@ -1034,6 +1047,7 @@ def main():
             over_ranks(m8["compute_only"]["wall"], dist.ReduceOp.MAX) / args.steps * 1e3,
             note="BASELINE's sharded configuration: %d groups x %d peers block-partitioned over the ranks (strong scaling)" % (total8, n))
         failed = failed or not ok8
+        state["main_line"] = None
         sets, ex, consumer = m8["sets"], m8["ex"], m8["consumer"]
     if rank == 0:
         plain = world == 1 and args.workload == "fused" and args.layout == "i32" and args.what == "fused"

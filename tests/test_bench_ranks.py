@@ -63,6 +63,24 @@ def test_a_rank_that_stops_making_progress_ends_the_run_with_a_diagnosis():
 
 
 @pytest.mark.gpu
+def test_a_stuck_additional_leg_does_not_cost_the_line():
+    """Rank 1 stops inside the strong-scaling leg that follows the headline's measurement at 2 and 4
+    ranks: the watchdog ends the run with a non-zero code, and rank 0's line still goes out complete
+    (verified figures of the headline), with the leg's place saying what happened."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["RQ_BENCH_INJECT_HANG"] = "1:6:strong_8m"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                        "--groups", "65536", "--strong-total", "131072", "--steps", "16", "--warmup", "4",
+                        "--no-cpu-baseline", "--watchdog-seconds", "6"], capture_output=True, text=True, timeout=280, env=env)
+    assert p.returncode != 0
+    assert "watchdog: rank" in p.stderr and "strong_8m:timed" in p.stderr, p.stderr[-3000:]
+    r = json.loads(p.stdout.strip().splitlines()[-1])
+    assert "valid" not in r and r["verified"]["ok"] and r["n_gpus"] == 2 and r["value"] > 0
+    assert r["extra"]["compute_only"]["value"] > 0
+    assert "stopped making progress" in r["extra"]["strong_8m"]["error"]
+
+
+@pytest.mark.gpu
 def test_bench_refuses_more_rccl_ranks_than_gpus():
     import torch
     n = torch.cuda.device_count() + 1
