@@ -807,6 +807,8 @@ def main():
             workload = "%d groups, mixed 3-9 peers + 10%% joint consensus, Zipf log lengths" % G
 
         debug = bool(os.environ.get("RQ_BENCH_DEBUG"))
+        prepared = {}
+        stream_handle = torch.cuda.current_stream(device).cuda_stream      # the launches' stream for the whole measurement
 
         def step(i, with_ex=True):
             s = i % S
@@ -820,12 +822,14 @@ def main():
                 time.sleep(1e6)                  # test hook: this rank never gets to its next collective
             if x is not None and s % R == 0:
                 x.begin(s // R)                  # the slot's previous all-gather must be done
-            if args.what == "fused":
-                eng.fused_round(sets[s], variant=args.variant, want_bits=not args.no_bits, status=not args.no_status)
-            elif args.what == "commit":
-                eng.commit_advance(sets[s], variant=args.variant)
-            else:
-                eng.vote_tally(sets[s], variant=args.variant)
+            plan = prepared.get(s)
+            if plan is None:             # validated once per set, like a C or Go host that keeps its rq_plan handles
+                if args.what == "fused":
+                    plan = eng.prepare(sets[s], 3, args.variant, want_bits=not args.no_bits, status=not args.no_status)
+                else:
+                    plan = eng.prepare(sets[s], 1 if args.what == "commit" else 2, args.variant)
+                prepared[s] = plan
+            eng.launch_prepared(plan, stream_handle)
             if x is not None and s % R == 0:
                 x.round_started((s // R - 1) % depth)
             elif ex is not None and s % R == 0:

@@ -520,10 +520,11 @@ class DeviceEngine:
                 d.seg_n[i] = v
         return d
 
-    def round(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
-        """Enqueue the commit (what & 1) and/or vote (what & 2) decision for DeviceBatch b
-        on torch's current stream.  The descriptor is validated once into an rq_plan
-        per (batch, options); every later call is a two-argument rq_plan_launch."""
+    def prepare(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """The prepared launch (rq_plan handle) of the commit (what & 1) and/or vote (what & 2)
+        decision for DeviceBatch b: the descriptor is validated once per (batch, options) and the
+        plan kept with the batch.  A caller in a tight loop holds the handle and calls
+        launch_prepared() -- two arguments per launch, as a C or Go host would."""
         # everything the descriptor bakes in besides the batch's own arrays: a field reassigned
         # after the first launch (a signal word, a summary buffer) gets a plan of its own
         o = b.o
@@ -540,9 +541,19 @@ class DeviceEngine:
                 self._check(rc, "rq_plan_round")
             b._args[key] = plan
             b._plans.append((self._l, plan))
-        rc = self._l.rq_plan_launch(plan, torch.cuda.current_stream().cuda_stream)
+        return plan
+
+    def launch_prepared(self, plan, stream=None):
+        """rq_plan_launch of a handle from prepare() on `stream` (a raw stream handle; None =
+        torch's current stream)."""
+        rc = self._l.rq_plan_launch(plan, torch.cuda.current_stream().cuda_stream if stream is None else stream)
         if rc != 0:
             self._check(rc, "rq_plan_launch")
+
+    def round(self, b, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
+        """Enqueue the decision for DeviceBatch b on torch's current stream (prepare() on first
+        use, then a two-argument rq_plan_launch)."""
+        self.launch_prepared(self.prepare(b, what, variant, want_bits, status))
 
     def plan_rounds(self, batches, what=3, variant=VAR_DEFAULT, want_bits=True, status=True):
         """ONE prepared launch over several DeviceBatch images (rq_plan_rounds): each keeps its
